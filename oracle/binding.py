@@ -1,0 +1,172 @@
+"""ctypes binding of the CPU oracle (oracle/liboracle.so).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, by __graft_entry__.smoke() and by
+bench.py's cpu_baseline leg; never by the product package.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from path_tracer_amd import abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+RNG_COUNTER, RNG_SEQUENTIAL = 0, 1
+
+_lib = None
+
+
+def build(force: bool = False):
+    so = os.path.join(_HERE, "liboracle.so")
+    src = os.path.join(_HERE, "oracle.cpp")
+    if force or not os.path.exists(so) or (os.path.exists(src) and os.path.getmtime(src) > os.path.getmtime(so)):
+        subprocess.check_call(["make", "-C", _HERE, "liboracle.so"], stdout=subprocess.DEVNULL)
+    return so
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    so = os.path.join(_HERE, "liboracle.so")
+    if not os.path.exists(so):
+        build()
+    lib = C.CDLL(so)
+    vp, i64, dbl = C.c_void_p, C.c_int64, C.c_double
+    lib.orc_create.restype = vp
+    lib.orc_create.argtypes = [C.POINTER(abi.SceneDesc)]
+    lib.orc_destroy.argtypes = [vp]
+    lib.orc_last_error.restype = C.c_char_p
+    lib.orc_render.restype = C.c_int
+    lib.orc_render.argtypes = [vp, C.POINTER(abi.Params), C.c_int, C.c_int, vp, vp, C.POINTER(abi.Counters)]
+    lib.orc_trace_pixel.restype = C.c_int
+    lib.orc_trace_pixel.argtypes = [vp, C.POINTER(abi.Params), C.c_int, C.c_int, C.POINTER(dbl)]
+    for name in ("orc_intersect", "orc_intersect_brute"):
+        fn = getattr(lib, name)
+        fn.restype = C.c_int
+        fn.argtypes = [vp, i64, vp, vp, dbl, vp, vp, vp]
+    lib.orc_shadow_attenuation.restype = C.c_int
+    lib.orc_shadow_attenuation.argtypes = [vp, C.POINTER(abi.Params), C.c_int, i64, vp, vp, vp]
+    lib.orc_shade_brdf.restype = C.c_int
+    lib.orc_shade_brdf.argtypes = [vp, C.POINTER(abi.Params), C.c_int] + [C.POINTER(dbl)] * 5 + [C.c_uint64, C.POINTER(dbl)]
+    lib.orc_object_order.restype = C.c_int
+    lib.orc_object_order.argtypes = [vp, vp]
+    lib.orc_cubemap_color.restype = C.c_int
+    lib.orc_cubemap_color.argtypes = [vp, i64, vp, vp]
+    lib.orc_uniform.restype = dbl
+    lib.orc_uniform.argtypes = [C.c_uint64, C.c_uint64]
+    lib.orc_mix.restype = C.c_uint64
+    lib.orc_mix.argtypes = [C.c_uint64, C.c_uint64]
+    lib.orc_sample_key.restype = C.c_uint64
+    lib.orc_sample_key.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64]
+    _lib = lib
+    return lib
+
+
+def _d3(v):
+    return (C.c_double * 3)(*[float(x) for x in v])
+
+
+class Oracle:
+    """The reference renderer's object graph for one scene, on the CPU."""
+
+    def __init__(self, scene):
+        self.lib = load()
+        desc, keep = scene.to_c()
+        self._h = self.lib.orc_create(C.byref(desc))
+        del keep
+        if not self._h:
+            raise RuntimeError("orc_create: " + self.lib.orc_last_error().decode())
+        self.n_objects = len(scene.objects)
+
+    def close(self):
+        if self._h:
+            self.lib.orc_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def render(self, params, threads=1, rng_mode=RNG_COUNTER, want_rgb8=False, want_counters=False):
+        w, h = params.width, params.height
+        mean = np.zeros((h, w, 3), dtype=np.float64)
+        rgb8 = np.zeros((h, w, 3), dtype=np.uint8) if want_rgb8 else None
+        cnt = abi.Counters()
+        rc = self.lib.orc_render(self._h, C.byref(params), threads, rng_mode, mean.ctypes.data,
+                                 rgb8.ctypes.data if want_rgb8 else None, C.byref(cnt))
+        if rc != 0:
+            raise RuntimeError(f"orc_render rc={rc}: " + self.lib.orc_last_error().decode())
+        out = [mean]
+        if want_rgb8:
+            out.append(rgb8)
+        if want_counters:
+            out.append(cnt.as_dict())
+        return out[0] if len(out) == 1 else tuple(out)
+
+    def trace_pixel(self, params, i, j):
+        out = (C.c_double * 3)()
+        rc = self.lib.orc_trace_pixel(self._h, C.byref(params), i, j, out)
+        if rc != 0:
+            raise RuntimeError(f"orc_trace_pixel rc={rc}")
+        return np.array(out[:])
+
+    def intersect(self, org, dir, t_max=1000.0, brute=False):
+        org = np.ascontiguousarray(org, dtype=np.float64).reshape(-1, 3)
+        dir = np.ascontiguousarray(dir, dtype=np.float64).reshape(-1, 3)
+        n = org.shape[0]
+        t = np.empty(n, dtype=np.float64)
+        prim = np.empty(n, dtype=np.int32)
+        nrm = np.empty((n, 3), dtype=np.float64)
+        fn = self.lib.orc_intersect_brute if brute else self.lib.orc_intersect
+        rc = fn(self._h, n, org.ctypes.data, dir.ctypes.data, t_max, t.ctypes.data, prim.ctypes.data, nrm.ctypes.data)
+        if rc != 0:
+            raise RuntimeError(f"orc_intersect rc={rc}")
+        return t, prim, nrm
+
+    def shadow_attenuation(self, params, light, fire, keys=None):
+        fire = np.ascontiguousarray(fire, dtype=np.float64).reshape(-1, 3)
+        n = fire.shape[0]
+        keys = np.zeros(n, dtype=np.uint64) if keys is None else np.ascontiguousarray(keys, dtype=np.uint64)
+        out = np.empty((n, 3), dtype=np.float64)
+        rc = self.lib.orc_shadow_attenuation(self._h, C.byref(params), light, n, fire.ctypes.data, keys.ctypes.data, out.ctypes.data)
+        if rc != 0:
+            raise RuntimeError(f"orc_shadow_attenuation rc={rc}")
+        return out
+
+    def shade_brdf(self, params, material, P, N, V, w, Lin, key=0):
+        out = (C.c_double * 3)()
+        rc = self.lib.orc_shade_brdf(self._h, C.byref(params), material, _d3(P), _d3(N), _d3(V), _d3(w), _d3(Lin), key, out)
+        if rc != 0:
+            raise RuntimeError(f"orc_shade_brdf rc={rc}")
+        return np.array(out[:])
+
+    def object_order(self):
+        order = np.empty(self.n_objects, dtype=np.int32)
+        self.lib.orc_object_order(self._h, order.ctypes.data)
+        return order
+
+    def cubemap_color(self, dirs):
+        dirs = np.ascontiguousarray(dirs, dtype=np.float64).reshape(-1, 3)
+        out = np.empty_like(dirs)
+        rc = self.lib.orc_cubemap_color(self._h, dirs.shape[0], dirs.ctypes.data, out.ctypes.data)
+        if rc != 0:
+            raise RuntimeError("orc_cubemap_color failed (no cubemap?)")
+        return out
+
+
+def uniform(key, j):
+    return load().orc_uniform(key, j)
+
+
+def mix(key, j):
+    return load().orc_mix(key, j)
+
+
+def sample_key(seed, pixel, sample):
+    return load().orc_sample_key(seed, pixel, sample)
