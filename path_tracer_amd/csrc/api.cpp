@@ -1,0 +1,554 @@
+// api.cpp — the C ABI of libmipt (include/mipt.h): context, scene upload, and the
+// host loop that drives the wavefront kernels level by level.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/mipt.h"
+#include "kernels.h"
+#include "scene_build.h"
+
+using namespace mipt;
+
+namespace {
+thread_local std::string g_thread_err;
+
+struct DevBuf {
+  void *p = nullptr;
+  size_t bytes = 0;
+};
+}  // namespace
+
+struct mipt_ctx {
+  int device = 0;
+  std::string err;
+  bool have_scene = false;
+  HostScene host;  // kept only for its small tables (lights, stats); big arrays are freed after upload
+  SceneDev dev;
+  std::vector<void *> scene_allocs;
+  int64_t scene_bytes = 0;
+  int64_t n_prims = 0, n_nodes = 0;
+  std::vector<LightRec> lights_host;
+  int lights_area_samples = -1;
+
+  // render workspace
+  uint32_t capacity = 0;
+  DevBuf queue[2], shade, hits, accum, rows, counts, dcount;
+  mipt_counters totals{};
+};
+
+namespace {
+
+int set_err(mipt_ctx *c, int code, const char *fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  if (c) c->err = buf;
+  g_thread_err = buf;
+  return code;
+}
+
+#define HIP_TRY(ctx, call)                                                                       \
+  do {                                                                                           \
+    hipError_t e_ = (call);                                                                      \
+    if (e_ != hipSuccess)                                                                        \
+      return set_err(ctx, e_ == hipErrorOutOfMemory ? MIPT_ERR_NOMEM : MIPT_ERR_DEVICE, "%s: %s", #call, hipGetErrorString(e_)); \
+  } while (0)
+
+int ensure(mipt_ctx *c, DevBuf &b, size_t bytes) {
+  if (b.bytes >= bytes && b.p) return MIPT_OK;
+  if (b.p) {
+    HIP_TRY(c, hipFree(b.p));
+    b.p = nullptr;
+    b.bytes = 0;
+  }
+  if (bytes == 0) bytes = 16;
+  HIP_TRY(c, hipMalloc(&b.p, bytes));
+  b.bytes = bytes;
+  return MIPT_OK;
+}
+
+void release(DevBuf &b) {
+  if (b.p) (void)hipFree(b.p);
+  b.p = nullptr;
+  b.bytes = 0;
+}
+
+template <typename T>
+int upload(mipt_ctx *c, const std::vector<T> &v, const T **dst) {
+  *dst = nullptr;
+  size_t bytes = std::max<size_t>(v.size() * sizeof(T), 16);
+  void *p = nullptr;
+  HIP_TRY(c, hipMalloc(&p, bytes));
+  c->scene_allocs.push_back(p);
+  c->scene_bytes += (int64_t)bytes;
+  if (!v.empty()) HIP_TRY(c, hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+  *dst = reinterpret_cast<const T *>(p);
+  return MIPT_OK;
+}
+
+void free_scene(mipt_ctx *c) {
+  for (void *p : c->scene_allocs) (void)hipFree(p);
+  c->scene_allocs.clear();
+  c->scene_bytes = 0;
+  c->have_scene = false;
+}
+
+RayQueue carve_queue(void *base, uint32_t cap) {
+  RayQueue q;
+  double *d = reinterpret_cast<double *>(base);
+  q.ox = d + 0ull * cap; q.oy = d + 1ull * cap; q.oz = d + 2ull * cap;
+  q.dx = d + 3ull * cap; q.dy = d + 4ull * cap; q.dz = d + 5ull * cap;
+  q.tx = d + 6ull * cap; q.ty = d + 7ull * cap; q.tz = d + 8ull * cap;
+  q.key = reinterpret_cast<uint64_t *>(d + 9ull * cap);
+  q.slot = reinterpret_cast<uint32_t *>(d + 10ull * cap);
+  return q;
+}
+ShadeList carve_shade(void *base, uint32_t cap) {
+  ShadeList s;
+  double *d = reinterpret_cast<double *>(base);
+  s.px = d + 0ull * cap; s.py = d + 1ull * cap; s.pz = d + 2ull * cap;
+  s.nx = d + 3ull * cap; s.ny = d + 4ull * cap; s.nz = d + 5ull * cap;
+  s.wx = d + 6ull * cap; s.wy = d + 7ull * cap; s.wz = d + 8ull * cap;
+  s.key = reinterpret_cast<uint64_t *>(d + 9ull * cap);
+  s.slot = reinterpret_cast<uint32_t *>(d + 10ull * cap);
+  return s;
+}
+constexpr size_t kEntryBytes = 10 * sizeof(double) + sizeof(uint32_t);  // per queue / shade-list entry
+
+int check_params(mipt_ctx *c, const mipt_params *p) {
+  if (!p) return set_err(c, MIPT_ERR_INVALID, "null params");
+  if (p->width <= 0 || p->height <= 0) return set_err(c, MIPT_ERR_INVALID, "width and height must be positive");
+  if ((int64_t)p->width * p->height > (1ll << 30)) return set_err(c, MIPT_ERR_LIMIT, "frame larger than 2^30 pixels");
+  if (p->spp <= 0) return set_err(c, MIPT_ERR_INVALID, "spp must be positive");
+  if (p->area_samples <= 0 || p->area_samples > 4096) return set_err(c, MIPT_ERR_INVALID, "area_samples must be in 1..4096");
+  if (!(p->rr_q >= 0.0 && p->rr_q < 1.0)) return set_err(c, MIPT_ERR_INVALID, "rr_q must be in [0, 1)");
+  if (!(p->t_max > 0.0)) return set_err(c, MIPT_ERR_INVALID, "t_max must be positive");
+  if (p->max_depth <= 0 || p->max_depth > 4096) return set_err(c, MIPT_ERR_INVALID, "max_depth must be in 1..4096");
+  if (p->shard_count < 1 || p->shard_index < 0 || p->shard_index >= p->shard_count || p->band_rows < 1)
+    return set_err(c, MIPT_ERR_INVALID, "bad shard parameters");
+  if (p->sample_begin < 0 || p->sample_end > p->spp || p->sample_begin > p->sample_end)
+    return set_err(c, MIPT_ERR_INVALID, "bad sample range");
+  if (p->batch_samples < 0) return set_err(c, MIPT_ERR_INVALID, "batch_samples must be >= 0");
+  return MIPT_OK;
+}
+
+RenderConst make_const(const mipt_params *p, uint32_t capacity) {
+  RenderConst rc;
+  rc.width = p->width;
+  rc.height = p->height;
+  rc.area_samples = p->area_samples;
+  rc.max_depth = p->max_depth;
+  rc.rr_q = p->rr_q;
+  rc.t_max = p->t_max;
+  rc.seed = p->seed;
+  rc.flags = p->flags;
+  rc.capacity = capacity;
+  return rc;
+}
+
+// The per-hit shadow-ray block depends on area_samples: re-upload the light table
+// when it changes.
+int sync_lights(mipt_ctx *c, int area_samples) {
+  if (c->lights_area_samples == area_samples) return MIPT_OK;
+  int first = 0;
+  for (LightRec &L : c->lights_host) {
+    L.samples = (L.type == MIPT_LIGHT_RECT_AREA) ? area_samples : 1;
+    L.first_ray = first;
+    first += L.samples;
+  }
+  c->dev.rays_per_hit = first;
+  if (!c->lights_host.empty())
+    HIP_TRY(c, hipMemcpy(const_cast<LightRec *>(c->dev.lights), c->lights_host.data(), c->lights_host.size() * sizeof(LightRec), hipMemcpyHostToDevice));
+  c->lights_area_samples = area_samples;
+  return MIPT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mipt_version(void) { return MIPT_VERSION; }
+
+const char *mipt_last_error(const mipt_ctx *ctx) { return ctx ? ctx->err.c_str() : g_thread_err.c_str(); }
+
+void mipt_default_params(mipt_params *p, int width, int height) {
+  if (!p) return;
+  std::memset(p, 0, sizeof(*p));
+  p->width = width;
+  p->height = height;
+  p->spp = 100;          // RayTracer.cpp:61
+  p->area_samples = 10;  // light.cpp:118
+  p->rr_q = 0.1;         // RayTracer.cpp:229
+  p->t_max = 1000.0;     // scene.cpp:129
+  p->max_depth = 64;
+  p->flags = 0;
+  p->seed = 1;
+  p->shard_index = 0;
+  p->shard_count = 1;
+  p->band_rows = 8;
+  p->sample_begin = 0;
+  p->sample_end = p->spp;
+  p->batch_samples = 0;
+}
+
+int mipt_create(mipt_ctx **out, int device) {
+  if (!out) return set_err(nullptr, MIPT_ERR_INVALID, "null out pointer");
+  *out = nullptr;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0) return set_err(nullptr, MIPT_ERR_DEVICE, "no HIP device available (%s)", hipGetErrorString(e));
+  if (device < 0 || device >= n) return set_err(nullptr, MIPT_ERR_INVALID, "device %d out of range (have %d)", device, n);
+  mipt_ctx *c = new (std::nothrow) mipt_ctx();
+  if (!c) return set_err(nullptr, MIPT_ERR_NOMEM, "out of host memory");
+  c->device = device;
+  std::memset(&c->dev, 0, sizeof(c->dev));
+  *out = c;
+  return MIPT_OK;
+}
+
+void mipt_destroy(mipt_ctx *c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  free_scene(c);
+  release(c->queue[0]);
+  release(c->queue[1]);
+  release(c->shade);
+  release(c->hits);
+  release(c->accum);
+  release(c->rows);
+  release(c->counts);
+  release(c->dcount);
+  delete c;
+}
+
+int mipt_upload_scene(mipt_ctx *c, const mipt_scene_desc *desc) {
+  if (!c) return set_err(nullptr, MIPT_ERR_INVALID, "null context");
+  HIP_TRY(c, hipSetDevice(c->device));
+  free_scene(c);
+  std::string err;
+  HostScene &H = c->host;
+  int rcode;
+  try {
+    rcode = build_host_scene(desc, &H, &err);
+  } catch (const std::bad_alloc &) {
+    return set_err(c, MIPT_ERR_NOMEM, "out of host memory while building the scene");
+  }
+  if (rcode != MIPT_OK) return set_err(c, rcode, "%s", err.c_str());
+  SceneDev &D = c->dev;
+  std::memset(&D, 0, sizeof(D));
+  int r;
+  if ((r = upload(c, H.nodes, &D.nodes)) != MIPT_OK) return r;
+  if ((r = upload(c, H.tris, &D.tris)) != MIPT_OK) return r;
+  if (!H.tri_normals.empty()) {
+    if ((r = upload(c, H.tri_normals, &D.tri_normals)) != MIPT_OK) return r;
+  }
+  if ((r = upload(c, H.prim_info, &D.prim_info)) != MIPT_OK) return r;
+  if ((r = upload(c, H.ref_order, &D.ref_order)) != MIPT_OK) return r;
+  if ((r = upload(c, H.objects, &D.objects)) != MIPT_OK) return r;
+  if ((r = upload(c, H.materials, &D.materials)) != MIPT_OK) return r;
+  if ((r = upload(c, H.lights, &D.lights)) != MIPT_OK) return r;
+  D.n_lights = (int)H.lights.size();
+  D.n_materials = (int)H.materials.size();
+  D.n_prims = (int)H.prim_info.size();
+  D.stack_entries = H.max_depth + 2;
+  D.translucent = H.translucent ? 1 : 0;
+  D.radius = H.radius;
+  std::memcpy(D.ambient, H.ambient, sizeof(D.ambient));
+  D.camera = H.camera;
+  D.has_cubemap = H.has_cubemap ? 1 : 0;
+  if (H.has_cubemap) {
+    for (int f = 0; f < 6; f++) {
+      const uint8_t *p = nullptr;
+      if ((r = upload(c, H.cube_rgb[f], &p)) != MIPT_OK) return r;
+      D.cube[f] = p;
+      D.cube_w[f] = H.cube_w[f];
+      D.cube_h[f] = H.cube_h[f];
+    }
+  }
+  if ((size_t)D.stack_entries * 256 * 4 > 64 * 1024)
+    return set_err(c, MIPT_ERR_LIMIT, "BVH too deep for the LDS traversal stack (%d levels)", H.max_depth);
+  c->n_prims = (int64_t)H.prim_info.size();
+  c->n_nodes = (int64_t)H.nodes.size();
+  c->lights_host = H.lights;
+  c->lights_area_samples = -1;
+  // drop the big host copies
+  std::vector<Node>().swap(H.nodes);
+  std::vector<Tri>().swap(H.tris);
+  std::vector<TriNormals>().swap(H.tri_normals);
+  std::vector<uint32_t>().swap(H.prim_info);
+  std::vector<uint32_t>().swap(H.ref_order);
+  for (int f = 0; f < 6; f++) std::vector<uint8_t>().swap(H.cube_rgb[f]);
+  c->have_scene = true;
+  return MIPT_OK;
+}
+
+int mipt_render_accumulate(mipt_ctx *c, const mipt_params *p, double *d_sum, void *stream) {
+  if (!c) return set_err(nullptr, MIPT_ERR_INVALID, "null context");
+  if (!c->have_scene) return set_err(c, MIPT_ERR_NOSCENE, "no scene uploaded");
+  int r = check_params(c, p);
+  if (r != MIPT_OK) return r;
+  if (!d_sum) return set_err(c, MIPT_ERR_INVALID, "null d_sum");
+  HIP_TRY(c, hipSetDevice(c->device));
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if ((r = sync_lights(c, p->area_samples)) != MIPT_OK) return r;
+  bool count = (p->flags & MIPT_FLAG_COUNTERS) != 0;
+
+  // rows owned by this shard
+  std::vector<int> rows;
+  for (int j = 0; j < p->height; j++)
+    if ((j / p->band_rows) % p->shard_count == p->shard_index) rows.push_back(j);
+  int ns_total = p->sample_end - p->sample_begin;
+  int64_t owned = (int64_t)rows.size() * p->width;
+  if (owned == 0 || ns_total == 0) return MIPT_OK;
+
+  // batch geometry: SB samples of PB pixels per batch, PB*SB <= B
+  int64_t B = p->batch_samples > 0 ? p->batch_samples : (1ll << 22);
+  int SB = (int)std::min<int64_t>(ns_total, B);
+  int64_t PB = std::max<int64_t>(1, B / SB);
+  PB = std::min<int64_t>(PB, owned);
+  int64_t batch = PB * SB;
+  if (2 * batch + 1024 > 0x7fffffffll) return set_err(c, MIPT_ERR_LIMIT, "batch_samples too large");
+  uint32_t cap = (uint32_t)(2 * batch + 1024);
+  c->capacity = cap;
+  if ((r = ensure(c, c->queue[0], (size_t)cap * kEntryBytes + 64)) != MIPT_OK) return r;
+  if ((r = ensure(c, c->queue[1], (size_t)cap * kEntryBytes + 64)) != MIPT_OK) return r;
+  if ((r = ensure(c, c->shade, (size_t)cap * kEntryBytes + 64)) != MIPT_OK) return r;
+  if ((r = ensure(c, c->hits, (size_t)cap * (sizeof(double) + sizeof(int)) + 64)) != MIPT_OK) return r;
+  if ((r = ensure(c, c->accum, (size_t)batch * 3 * sizeof(double))) != MIPT_OK) return r;
+  if ((r = ensure(c, c->rows, rows.size() * sizeof(int))) != MIPT_OK) return r;
+  if ((r = ensure(c, c->counts, sizeof(BatchCounts))) != MIPT_OK) return r;
+  if (!c->dcount.p) {
+    if ((r = ensure(c, c->dcount, sizeof(DeviceCounters))) != MIPT_OK) return r;
+    HIP_TRY(c, hipMemset(c->dcount.p, 0, sizeof(DeviceCounters)));
+  }
+  HIP_TRY(c, hipMemcpyAsync(c->rows.p, rows.data(), rows.size() * sizeof(int), hipMemcpyHostToDevice, st));
+  HIP_TRY(c, hipStreamSynchronize(st));  // `rows` is a local vector
+
+  RenderConst rc = make_const(p, cap);
+  RayQueue q[2] = {carve_queue(c->queue[0].p, cap), carve_queue(c->queue[1].p, cap)};
+  ShadeList sl = carve_shade(c->shade.p, cap);
+  double *hit_t = reinterpret_cast<double *>(c->hits.p);
+  int *hit_prim = reinterpret_cast<int *>(hit_t + cap);
+  double *accum = reinterpret_cast<double *>(c->accum.p);
+  BatchCounts *bc = reinterpret_cast<BatchCounts *>(c->counts.p);
+  DeviceCounters *dc = reinterpret_cast<DeviceCounters *>(c->dcount.p);
+  const int *d_rows = reinterpret_cast<const int *>(c->rows.p);
+  mipt_counters &tot = c->totals;
+
+  for (int64_t p0 = 0; p0 < owned; p0 += PB) {
+    int npix = (int)std::min<int64_t>(PB, owned - p0);
+    for (int s0 = p->sample_begin; s0 < p->sample_end; s0 += SB) {
+      int ns = std::min(SB, p->sample_end - s0);
+      uint32_t n = (uint32_t)((int64_t)npix * ns);
+      HIP_TRY(c, hipMemsetAsync(accum, 0, (size_t)n * 3 * sizeof(double), st));
+      launch_generate(c->dev, rc, d_rows, p0, npix, s0, ns, q[0], st);
+      if (count) { tot.samples += n; tot.ray_stages += n; }
+      int cur = 0;
+      for (int depth = 0; n > 0 && depth < p->max_depth; depth++) {
+        HIP_TRY(c, hipMemsetAsync(bc, 0, sizeof(BatchCounts), st));
+        launch_intersect(c->dev, rc, q[cur], n, hit_t, hit_prim, dc, count, st);
+        launch_shade(c->dev, rc, q[cur], n, hit_t, hit_prim, depth, q[cur ^ 1], sl, bc, accum, dc, count, st);
+        BatchCounts h;
+        HIP_TRY(c, hipMemcpyAsync(&h, bc, sizeof(h), hipMemcpyDeviceToHost, st));
+        HIP_TRY(c, hipStreamSynchronize(st));
+        if (h.overflow || h.next_rays > cap || h.shades > cap)
+          return set_err(c, MIPT_ERR_LIMIT,
+                         "path tree outgrew the ray queue at depth %d (%u rays, capacity %u): lower max_depth or batch_samples",
+                         depth, h.next_rays, cap);
+        if (count) {
+          tot.path_rays += n;
+          tot.ray_stages += 2ull * n + h.shades;
+          tot.shadow_rays += (uint64_t)h.shades * (uint64_t)c->dev.rays_per_hit;
+        }
+        if (h.shades) launch_shadow(c->dev, rc, sl, h.shades, accum, dc, count, st);
+        n = h.next_rays;
+        cur ^= 1;
+      }
+      launch_resolve(rc, accum, d_rows, p0, npix, ns, d_sum, dc, st);
+    }
+  }
+  HIP_TRY(c, hipStreamSynchronize(st));
+  HIP_TRY(c, hipGetLastError());
+  return MIPT_OK;
+}
+
+int mipt_resolve(mipt_ctx *c, const double *d_sum, int width, int height, int spp, float *d_rgb_f32, uint8_t *d_rgb8, void *stream) {
+  if (!c) return set_err(nullptr, MIPT_ERR_INVALID, "null context");
+  if (!d_sum || width <= 0 || height <= 0 || spp <= 0) return set_err(c, MIPT_ERR_INVALID, "bad resolve arguments");
+  HIP_TRY(c, hipSetDevice(c->device));
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  launch_finalize(d_sum, (int64_t)width * height, spp, d_rgb_f32, d_rgb8, st);
+  HIP_TRY(c, hipGetLastError());
+  return MIPT_OK;
+}
+
+int mipt_render(mipt_ctx *c, const mipt_params *p, float *rgb_f32, uint8_t *rgb8) {
+  if (!c) return set_err(nullptr, MIPT_ERR_INVALID, "null context");
+  if (!c->have_scene) return set_err(c, MIPT_ERR_NOSCENE, "no scene uploaded");
+  int r = check_params(c, p);
+  if (r != MIPT_OK) return r;
+  HIP_TRY(c, hipSetDevice(c->device));
+  size_t npx = (size_t)p->width * p->height;
+  double *d_sum = nullptr;
+  float *d_f = nullptr;
+  uint8_t *d_b = nullptr;
+  HIP_TRY(c, hipMalloc((void **)&d_sum, npx * 3 * sizeof(double)));
+  auto cleanup = [&]() {
+    if (d_sum) (void)hipFree(d_sum);
+    if (d_f) (void)hipFree(d_f);
+    if (d_b) (void)hipFree(d_b);
+  };
+  hipError_t e = hipMemset(d_sum, 0, npx * 3 * sizeof(double));  // traceSetup zero-fill, RayTracer.cpp:427
+  if (e == hipSuccess && rgb_f32) e = hipMalloc((void **)&d_f, npx * 3 * sizeof(float));
+  if (e == hipSuccess && rgb8) e = hipMalloc((void **)&d_b, npx * 3);
+  if (e != hipSuccess) {
+    cleanup();
+    return set_err(c, MIPT_ERR_NOMEM, "device allocation failed: %s", hipGetErrorString(e));
+  }
+  r = mipt_render_accumulate(c, p, d_sum, nullptr);
+  if (r == MIPT_OK) r = mipt_resolve(c, d_sum, p->width, p->height, p->spp, d_f, d_b, nullptr);
+  if (r == MIPT_OK) {
+    if (rgb_f32) e = hipMemcpy(rgb_f32, d_f, npx * 3 * sizeof(float), hipMemcpyDeviceToHost);
+    if (e == hipSuccess && rgb8) e = hipMemcpy(rgb8, d_b, npx * 3, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e != hipSuccess) r = set_err(c, MIPT_ERR_DEVICE, "copy back failed: %s", hipGetErrorString(e));
+  }
+  cleanup();
+  return r;
+}
+
+int mipt_trace_pixel(mipt_ctx *c, const mipt_params *p, int i, int j, double out[3]) {
+  if (!c) return set_err(nullptr, MIPT_ERR_INVALID, "null context");
+  if (!c->have_scene) {  // tracePixel returns black without a scene, RayTracer.cpp:63-64
+    if (out) out[0] = out[1] = out[2] = 0.0;
+    return set_err(c, MIPT_ERR_NOSCENE, "no scene uploaded");
+  }
+  int r = check_params(c, p);
+  if (r != MIPT_OK) return r;
+  if (!out || i < 0 || j < 0 || i >= p->width || j >= p->height) return set_err(c, MIPT_ERR_INVALID, "pixel out of range");
+  // one-row frame view: shard the frame so that only row j is owned, then read pixel i
+  mipt_params q = *p;
+  q.shard_count = p->height;
+  q.shard_index = j;
+  q.band_rows = 1;
+  q.sample_begin = 0;
+  q.sample_end = p->spp;
+  HIP_TRY(c, hipSetDevice(c->device));
+  size_t npx = (size_t)p->width * p->height;
+  double *d_sum = nullptr;
+  HIP_TRY(c, hipMalloc((void **)&d_sum, npx * 3 * sizeof(double)));
+  hipError_t e = hipMemset(d_sum, 0, npx * 3 * sizeof(double));
+  if (e != hipSuccess) { (void)hipFree(d_sum); return set_err(c, MIPT_ERR_DEVICE, "memset failed"); }
+  r = mipt_render_accumulate(c, &q, d_sum, nullptr);
+  double px[3] = {0, 0, 0};
+  if (r == MIPT_OK) {
+    e = hipMemcpy(px, d_sum + 3 * ((size_t)i + (size_t)j * p->width), sizeof(px), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) r = set_err(c, MIPT_ERR_DEVICE, "copy back failed");
+  }
+  (void)hipFree(d_sum);
+  if (r == MIPT_OK)
+    for (int k = 0; k < 3; k++) out[k] = px[k] / (double)p->spp;
+  return r;
+}
+
+int mipt_intersect(mipt_ctx *c, int64_t n, const double *org, const double *dir, double t_max, double *t, int32_t *prim, double *normal) {
+  if (!c) return set_err(nullptr, MIPT_ERR_INVALID, "null context");
+  if (!c->have_scene) return set_err(c, MIPT_ERR_NOSCENE, "no scene uploaded");
+  if (n < 0 || (n > 0 && (!org || !dir || !t || !prim || !normal))) return set_err(c, MIPT_ERR_INVALID, "bad arguments");
+  if (n == 0) return MIPT_OK;
+  HIP_TRY(c, hipSetDevice(c->device));
+  double *d_org = nullptr, *d_dir = nullptr, *d_t = nullptr, *d_n = nullptr;
+  int *d_p = nullptr;
+  size_t v3 = (size_t)n * 3 * sizeof(double);
+  hipError_t e = hipMalloc((void **)&d_org, v3);
+  if (e == hipSuccess) e = hipMalloc((void **)&d_dir, v3);
+  if (e == hipSuccess) e = hipMalloc((void **)&d_n, v3);
+  if (e == hipSuccess) e = hipMalloc((void **)&d_t, (size_t)n * sizeof(double));
+  if (e == hipSuccess) e = hipMalloc((void **)&d_p, (size_t)n * sizeof(int));
+  if (e == hipSuccess) e = hipMemcpy(d_org, org, v3, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(d_dir, dir, v3, hipMemcpyHostToDevice);
+  if (e == hipSuccess) {
+    launch_intersect_rays(c->dev, n, d_org, d_dir, t_max, d_t, d_p, d_n, nullptr);
+    e = hipDeviceSynchronize();
+  }
+  if (e == hipSuccess) e = hipMemcpy(t, d_t, (size_t)n * sizeof(double), hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemcpy(prim, d_p, (size_t)n * sizeof(int), hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemcpy(normal, d_n, v3, hipMemcpyDeviceToHost);
+  (void)hipFree(d_org); (void)hipFree(d_dir); (void)hipFree(d_n); (void)hipFree(d_t); (void)hipFree(d_p);
+  if (e != hipSuccess) return set_err(c, MIPT_ERR_DEVICE, "mipt_intersect: %s", hipGetErrorString(e));
+  return MIPT_OK;
+}
+
+int mipt_shadow_attenuation(mipt_ctx *c, const mipt_params *p, int light, int64_t n, const double *fire, const uint64_t *key, double *out) {
+  if (!c) return set_err(nullptr, MIPT_ERR_INVALID, "null context");
+  if (!c->have_scene) return set_err(c, MIPT_ERR_NOSCENE, "no scene uploaded");
+  int r = check_params(c, p);
+  if (r != MIPT_OK) return r;
+  if (light < 0 || light >= c->dev.n_lights) return set_err(c, MIPT_ERR_INVALID, "light index out of range");
+  if (n < 0 || (n > 0 && (!fire || !key || !out))) return set_err(c, MIPT_ERR_INVALID, "bad arguments");
+  if (n == 0) return MIPT_OK;
+  HIP_TRY(c, hipSetDevice(c->device));
+  if ((r = sync_lights(c, p->area_samples)) != MIPT_OK) return r;
+  RenderConst rc = make_const(p, 0);
+  double *d_f = nullptr, *d_o = nullptr;
+  uint64_t *d_k = nullptr;
+  size_t v3 = (size_t)n * 3 * sizeof(double);
+  hipError_t e = hipMalloc((void **)&d_f, v3);
+  if (e == hipSuccess) e = hipMalloc((void **)&d_o, v3);
+  if (e == hipSuccess) e = hipMalloc((void **)&d_k, (size_t)n * sizeof(uint64_t));
+  if (e == hipSuccess) e = hipMemcpy(d_f, fire, v3, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(d_k, key, (size_t)n * sizeof(uint64_t), hipMemcpyHostToDevice);
+  if (e == hipSuccess) {
+    launch_shadow_attenuation(c->dev, rc, light, n, d_f, d_k, d_o, nullptr);
+    e = hipDeviceSynchronize();
+  }
+  if (e == hipSuccess) e = hipMemcpy(out, d_o, v3, hipMemcpyDeviceToHost);
+  (void)hipFree(d_f); (void)hipFree(d_o); (void)hipFree(d_k);
+  if (e != hipSuccess) return set_err(c, MIPT_ERR_DEVICE, "mipt_shadow_attenuation: %s", hipGetErrorString(e));
+  return MIPT_OK;
+}
+
+int mipt_get_counters(mipt_ctx *c, mipt_counters *out) {
+  if (!c || !out) return set_err(c, MIPT_ERR_INVALID, "null argument");
+  *out = c->totals;
+  if (c->dcount.p) {
+    HIP_TRY(c, hipSetDevice(c->device));
+    DeviceCounters d;
+    HIP_TRY(c, hipMemcpy(&d, c->dcount.p, sizeof(d), hipMemcpyDeviceToHost));
+    out->node_visits = d.node_visits;
+    out->prim_tests = d.prim_tests;
+    out->shaded_hits = d.shaded_hits;
+    out->nan_samples = d.nan_samples;
+  }
+  return MIPT_OK;
+}
+
+int mipt_reset_counters(mipt_ctx *c) {
+  if (!c) return set_err(nullptr, MIPT_ERR_INVALID, "null context");
+  c->totals = mipt_counters{};
+  if (c->dcount.p) {
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipMemset(c->dcount.p, 0, sizeof(DeviceCounters)));
+  }
+  return MIPT_OK;
+}
+
+int mipt_scene_stats(mipt_ctx *c, int64_t *n_prims, int64_t *n_nodes, int64_t *device_bytes) {
+  if (!c) return set_err(nullptr, MIPT_ERR_INVALID, "null context");
+  if (!c->have_scene) return set_err(c, MIPT_ERR_NOSCENE, "no scene uploaded");
+  if (n_prims) *n_prims = c->n_prims;
+  if (n_nodes) *n_nodes = c->n_nodes;
+  if (device_bytes) *device_bytes = c->scene_bytes;
+  return MIPT_OK;
+}
+
+}  // extern "C"

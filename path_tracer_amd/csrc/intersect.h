@@ -1,0 +1,296 @@
+// intersect.h — closest-hit / any-hit traversal of the flat BVH and the fp64
+// primitive tests.  Replaces Scene::intersect (scene/scene.cpp:114-138) and what it
+// calls: BVH::checkIntersect (scene/bvh.h:160-185), BoundingBox::intersect
+// (scene/bbox.cc:27-63), Geometry::intersect (scene/scene.cpp:13-40) and the
+// intersectLocal of Sphere / Box / Square / TrimeshFace.
+//
+// Result contract: the closest primitive hit with t < t_max, ties in t broken by the
+// reference's visiting order (ref_order) — what the reference's unordered, un-pruned
+// walk with `test.t < i.t` returns.  Box tests are fp32 and conservative (they may
+// only accept too much), so the result does not depend on the tree shape.
+#ifndef MIPT_INTERSECT_H_
+#define MIPT_INTERSECT_H_
+
+#include "device_math.h"
+#include "layout.h"
+
+namespace mipt {
+
+#define MIPT_RAY_EPSILON 0.00000001  // scene/ray.h:147
+
+struct SceneDev {
+  const Node *nodes;
+  const Tri *tris;
+  const TriNormals *tri_normals;  // may be null
+  const uint32_t *prim_info;
+  const uint32_t *ref_order;
+  const ObjRec *objects;
+  const MatRec *materials;
+  const LightRec *lights;
+  int n_lights;
+  int n_materials;
+  int n_prims;
+  int rays_per_hit;
+  int stack_entries;  // LDS traversal stack entries per lane
+  int translucent;
+  double radius;
+  double ambient[3];
+  CameraRec camera;
+  int has_cubemap;
+  const uint8_t *cube[6];
+  int cube_w[6], cube_h[6];
+};
+
+// ---- analytic primitives, local space --------------------------------------------
+// Each returns the local hit parameter (or a negative value for a miss) and the
+// local normal.
+
+// Sphere::intersectLocal, Sphere.cpp:9-40.
+__device__ __forceinline__ bool sphere_local(d3 p, d3 d, double &t, d3 &N) {
+  d = normalize(d);
+  d3 v = -p;
+  double b = dot(v, d);
+  double disc = b * b - dot(v, v) + 1;
+  if (disc < 0.0) return false;
+  disc = sqrt(disc);
+  double t2 = b + disc;
+  if (t2 <= MIPT_RAY_EPSILON) return false;
+  double t1 = b - disc;
+  t = (t1 > MIPT_RAY_EPSILON) ? t1 : t2;
+  N = normalize(p + t * d);
+  return true;
+}
+
+// Box::intersectLocal, Box.cpp:11-74.
+__device__ __forceinline__ bool box_local(d3 p, d3 d, double &t, d3 &N) {
+  double bestT = 1e100;
+  int bestIndex = -1;
+#pragma unroll
+  for (int it = 0; it < 6; it++) {
+    const int mod0 = it % 3;
+    double dm = comp(d, mod0);
+    if (dm == 0) continue;
+    double tt = ((double)(it / 3) - 0.5 - comp(p, mod0)) / dm;
+    if (tt < MIPT_RAY_EPSILON || tt > bestT) continue;
+    const int mod1 = (it + 1) % 3, mod2 = (it + 2) % 3;
+    double x = comp(p, mod1) + tt * comp(d, mod1);
+    double y = comp(p, mod2) + tt * comp(d, mod2);
+    if (x <= 0.5 && x >= -0.5 && y <= 0.5 && y >= -0.5) {
+      if (bestT > tt) {
+        bestT = tt;
+        bestIndex = it;
+      }
+    }
+  }
+  if (bestIndex < 0) return false;
+  t = bestT;
+  double s = bestIndex < 3 ? -1.0 : 1.0;
+  int ax = bestIndex % 3;
+  // the reference writes -double(bestIndex == k): the untouched components are -0.0
+  // for the negative faces; the sign of zero never reaches a result
+  N = d3{ax == 0 ? s : 0.0, ax == 1 ? s : 0.0, ax == 2 ? s : 0.0};
+  return true;
+}
+
+// Square::intersectLocal, Square.cpp:8-43.
+__device__ __forceinline__ bool square_local(d3 p, d3 d, double &t, d3 &N) {
+  if (d.z == 0.0) return false;
+  double tt = -p.z / d.z;
+  if (tt <= MIPT_RAY_EPSILON) return false;
+  double px = p.x + tt * d.x, py = p.y + tt * d.y;
+  if (px < -0.5 || px > 0.5) return false;
+  if (py < -0.5 || py > 0.5) return false;
+  t = tt;
+  N = d3{0.0, 0.0, d.z > 0.0 ? -1.0 : 1.0};
+  return true;
+}
+
+// Geometry::intersect, scene.cpp:13-40, for the analytic kinds: world ray -> local,
+// intersectLocal, t back to world.  Nlocal is returned untransformed.
+__device__ __forceinline__ bool analytic_hit(const ObjRec *o, uint32_t kind, d3 org, d3 dir, double &t, d3 &Nlocal) {
+  d3 p = xform_point(o->inv, org);
+  d3 dl = xform_point(o->inv, org + dir) - p;
+  double len = length(dl);
+  dl = normalize(dl);
+  double tl;
+  bool hit;
+  if (kind == KIND_SPHERE) hit = sphere_local(p, dl, tl, Nlocal);
+  else if (kind == KIND_BOX) hit = box_local(p, dl, tl, Nlocal);
+  else hit = square_local(p, dl, tl, Nlocal);
+  if (!hit) return false;
+  t = tl / len;
+  return true;
+}
+
+// TrimeshFace::intersectLocal, trimesh.cpp:98-200, on the world-space triangle.
+// w1/w2 are the barycentric weights of the second and third vertex.
+__device__ __forceinline__ bool tri_hit(const Tri *tr, d3 org, d3 dir, double &t, double &w1, double &w2) {
+  d3 n = ld3(tr->n);
+  double denom = dot(n, dir);
+  if (fabs(denom) < MIPT_RAY_EPSILON) return false;
+  d3 a = ld3(tr->a);
+  double num = dot(a - org, n);
+  double tt = num / denom;
+  if (!(tt >= 0)) return false;
+  d3 pa = (org + tt * dir) - a;
+  double b1 = dot(pa, ld3(tr->q1));
+  double b2 = dot(pa, ld3(tr->q2));
+  double b0 = 1 - b1 - b2;
+  if (!(b0 >= 0 && b0 <= 1 && b1 >= 0 && b1 <= 1 && b2 >= 0 && b2 <= 1)) return false;
+  t = tt;
+  w1 = b1;
+  w2 = b2;
+  return true;
+}
+
+// ---- conservative fp32 slab culling --------------------------------------------
+// t_axis = b * id + off, with off lowered (near planes) or raised (far planes) by
+// pad = 2^-21 * (R + |o|) * |1/d|: more than the error of rounding the origin, the
+// reciprocal and the box to fp32.  Axis-parallel rays use |d| = 1e-30.
+struct Cull {
+  float idx, idy, idz;
+  float nx, ny, nz;  // near-plane offsets
+  float fx, fy, fz;  // far-plane offsets
+};
+
+__device__ __forceinline__ void cull_axis(double o, double d, double R, float &id, float &offN, float &offF) {
+  double dd = fabs(d) < 1e-30 ? copysign(1e-30, d) : d;
+  double inv = 1.0 / dd;
+  double oi = o * inv;
+  double pad = 4.76837158203125e-07 * (R + fabs(o)) * fabs(inv);
+  id = (float)inv;
+  offN = __double2float_rd(-(oi + pad));
+  offF = __double2float_ru(-(oi - pad));
+}
+
+__device__ __forceinline__ Cull make_cull(d3 o, d3 d, double R) {
+  Cull c;
+  cull_axis(o.x, d.x, R, c.idx, c.nx, c.fx);
+  cull_axis(o.y, d.y, R, c.idy, c.ny, c.fy);
+  cull_axis(o.z, d.z, R, c.idz, c.nz, c.fz);
+  return c;
+}
+
+// Entry distance of the ray into [mn, mx] (>= 0), or a value > tlimit on a miss.
+__device__ __forceinline__ float slab(const Cull &c, const float *mn, const float *mx, float tlimit) {
+  float ax = c.idx < 0.0f ? mx[0] : mn[0], bx = c.idx < 0.0f ? mn[0] : mx[0];
+  float ay = c.idy < 0.0f ? mx[1] : mn[1], by = c.idy < 0.0f ? mn[1] : mx[1];
+  float az = c.idz < 0.0f ? mx[2] : mn[2], bz = c.idz < 0.0f ? mn[2] : mx[2];
+  float tn = fmaxf(fmaxf(__fmaf_rn(ax, c.idx, c.nx), __fmaf_rn(ay, c.idy, c.ny)), fmaxf(__fmaf_rn(az, c.idz, c.nz), 0.0f));
+  float tf = fminf(fminf(__fmaf_rn(bx, c.idx, c.fx), __fmaf_rn(by, c.idy, c.fy)), fminf(__fmaf_rn(bz, c.idz, c.fz), tlimit));
+  // one rounding of each fma is left: a relative 2^-22 slack covers it
+  return (tn <= tf * 1.0000005f) ? tn : 3.0e38f;
+}
+
+struct Hit {
+  double t;
+  int prim;  // storage index, -1 = miss
+};
+
+struct TravCounters {
+  uint32_t nodes;
+  uint32_t prims;
+};
+
+// Closest hit (ANY = false) or first hit with t < tmax (ANY = true).
+// `stack` points at this lane's first LDS slot; consecutive entries are `stride`
+// words apart (one 4-byte column per lane: conflict-free).
+template <bool ANY, bool COUNT>
+__device__ __forceinline__ Hit traverse(const SceneDev &S, d3 org, d3 dir, double tmax, uint32_t *stack, int stride, TravCounters &tc) {
+  Hit best;
+  best.t = tmax;
+  best.prim = -1;
+  Cull c = make_cull(org, dir, S.radius);
+  float tlimit = __double2float_ru(tmax) * 1.0000005f;
+  int sp = 0;
+  int cur = 0;  // root is always an inner node
+  while (true) {
+    if (cur >= 0) {
+      const float4 *np = reinterpret_cast<const float4 *>(S.nodes + cur);
+      float4 q0 = np[0], q1 = np[1], q2 = np[2];
+      int4 q3 = *reinterpret_cast<const int4 *>(np + 3);
+      if (COUNT) tc.nodes++;
+      float lmin[3] = {q0.x, q0.y, q0.z}, lmax[3] = {q0.w, q1.x, q1.y};
+      float rmin[3] = {q1.z, q1.w, q2.x}, rmax[3] = {q2.y, q2.z, q2.w};
+      float tl = slab(c, lmin, lmax, tlimit);
+      float tr = slab(c, rmin, rmax, tlimit);
+      bool hl = tl < 2.0e38f, hr = tr < 2.0e38f;
+      if (hl && hr) {
+        int nearc = q3.x, farc = q3.y;
+        if (tr < tl) { nearc = q3.y; farc = q3.x; }
+        stack[sp * stride] = (uint32_t)farc;
+        sp++;
+        cur = nearc;
+      } else if (hl) {
+        cur = q3.x;
+      } else if (hr) {
+        cur = q3.y;
+      } else {
+        if (sp == 0) break;
+        sp--;
+        cur = (int)stack[sp * stride];
+      }
+      continue;
+    }
+    // leaf
+    uint32_t code = (uint32_t)~cur;
+    uint32_t first = code >> 3, count = (code & 7u) + 1u;
+    for (uint32_t k = 0; k < count; k++) {
+      uint32_t s = first + k;
+      uint32_t info = S.prim_info[s];
+      uint32_t kind = info >> 30;
+      double t;
+      bool hit;
+      if (COUNT) tc.prims++;
+      if (kind == KIND_TRI) {
+        double w1, w2;
+        hit = tri_hit(S.tris + s, org, dir, t, w1, w2);
+      } else {
+        d3 Nl;
+        hit = analytic_hit(S.objects + (info & 0x3fffffffu), kind, org, dir, t, Nl);
+      }
+      if (hit) {
+        bool closer = t < best.t;
+        if (!ANY && t == best.t && best.prim >= 0) closer = S.ref_order[s] < S.ref_order[best.prim];
+        if (closer) {
+          best.t = t;
+          best.prim = (int)s;
+          if (ANY) return best;
+          tlimit = __double2float_ru(t) * 1.0000005f;
+        }
+      }
+    }
+    if (sp == 0) break;
+    sp--;
+    cur = (int)stack[sp * stride];
+  }
+  return best;
+}
+
+// World-space unit normal of a hit, as isect::getN() holds it after
+// Geometry::intersect (scene.cpp:30-34).
+__device__ __forceinline__ d3 hit_normal(const SceneDev &S, int prim, d3 org, d3 dir) {
+  uint32_t info = S.prim_info[prim];
+  uint32_t kind = info >> 30;
+  const ObjRec *o = S.objects + (info & 0x3fffffffu);
+  if (kind == KIND_TRI) {
+    const Tri *tr = S.tris + prim;
+    if (o->smooth && S.tri_normals) {
+      double t, w1, w2;
+      if (tri_hit(tr, org, dir, t, w1, w2)) {
+        const TriNormals *vn = S.tri_normals + prim;
+        double w0 = 1 - w1 - w2;
+        d3 n = (ld3(vn->na) * w0 + ld3(vn->nb) * w1) + ld3(vn->nc) * w2;
+        return normalize(n);
+      }
+    }
+    return ld3(tr->n);
+  }
+  double t;
+  d3 Nl = d3{0, 0, 1};
+  analytic_hit(o, kind, org, dir, t, Nl);
+  return normalize(mul3(o->normi, Nl));
+}
+
+}  // namespace mipt
+#endif

@@ -1,0 +1,74 @@
+// kernels.h — launch interface between the C ABI (api.cpp) and the HIP kernels
+// (kernels.hip).  Device pointers only.
+#ifndef MIPT_KERNELS_H_
+#define MIPT_KERNELS_H_
+
+#include <hip/hip_runtime.h>
+
+#include "../../include/mipt.h"
+#include "intersect.h"
+
+namespace mipt {
+
+// Ray queue, structure of arrays: one path-tree edge per entry.
+struct RayQueue {
+  double *ox, *oy, *oz;  // origin
+  double *dx, *dy, *dz;  // unit direction
+  double *tx, *ty, *tz;  // throughput of the edge (what its radiance is multiplied by)
+  uint64_t *key;         // random-stream key of the path node this ray arrives at
+  uint32_t *slot;        // sample accumulator the edge deposits into
+};
+constexpr size_t kRayBytes = 9 * sizeof(double) + sizeof(uint64_t) + sizeof(uint32_t);
+
+// Shaded hits waiting for their shadow rays.
+struct ShadeList {
+  double *px, *py, *pz;  // hit point P
+  double *nx, *ny, *nz;  // normal
+  double *wx, *wy, *wz;  // T * kd / pi * (1 - metallic) / norm
+  uint64_t *key;
+  uint32_t *slot;
+};
+
+struct DeviceCounters {
+  unsigned long long path_rays, shadow_rays, shaded_hits, node_visits, prim_tests, ray_stages, nan_samples, samples;
+};
+
+struct BatchCounts {
+  uint32_t next_rays;  // entries appended to the next queue
+  uint32_t shades;     // entries appended to the shade list
+  uint32_t overflow;   // a queue was full
+  uint32_t pad;
+};
+
+struct RenderConst {
+  int width, height;
+  int area_samples;
+  int max_depth;
+  double rr_q;
+  double t_max;
+  uint64_t seed;
+  uint32_t flags;
+  uint32_t capacity;  // entries per queue / shade list
+};
+
+void launch_generate(const SceneDev &S, const RenderConst &rc, const int *rows, int64_t first_pixel, int n_pixels,
+                     int sample0, int n_samples, RayQueue q, hipStream_t st);
+void launch_intersect(const SceneDev &S, const RenderConst &rc, RayQueue q, uint32_t n, double *hit_t, int *hit_prim,
+                      DeviceCounters *dc, bool count, hipStream_t st);
+void launch_shade(const SceneDev &S, const RenderConst &rc, RayQueue q, uint32_t n, const double *hit_t,
+                  const int *hit_prim, int depth, RayQueue next, ShadeList sl, BatchCounts *bc, double *accum,
+                  DeviceCounters *dc, bool count, hipStream_t st);
+void launch_shadow(const SceneDev &S, const RenderConst &rc, ShadeList sl, uint32_t n_shades, double *accum,
+                   DeviceCounters *dc, bool count, hipStream_t st);
+void launch_resolve(const RenderConst &rc, const double *accum, const int *rows, int64_t first_pixel, int n_pixels,
+                    int n_samples, double *d_sum, DeviceCounters *dc, hipStream_t st);
+void launch_finalize(const double *d_sum, int64_t n_pixels, int spp, float *rgb_f32, uint8_t *rgb8, hipStream_t st);
+
+// Test hooks.
+void launch_intersect_rays(const SceneDev &S, int64_t n, const double *org, const double *dir, double t_max,
+                           double *t, int *prim, double *normal, hipStream_t st);
+void launch_shadow_attenuation(const SceneDev &S, const RenderConst &rc, int light, int64_t n, const double *fire,
+                               const uint64_t *key, double *out, hipStream_t st);
+
+}  // namespace mipt
+#endif

@@ -1,0 +1,569 @@
+// kernels.hip — the wavefront path-tracing kernels for gfx950.
+//
+//   generate  : camera rays                    (RayTracer::trace, RayTracer.cpp:46-52; camera.cpp:20-29)
+//   intersect : closest hit per queued ray     (Scene::intersect, scene.cpp:114-138)
+//   shade     : Russian roulette, bounce and mirror rays, BRDF terms that need no
+//               shadow ray, queue compaction   (RayTracer::tracePath, RayTracer.cpp:221-306;
+//                                               Material::shadeBRDF, material.cpp:88-170)
+//   shadow    : one lane per shadow ray, in-wave segmented sum per hit
+//                                              (Light::shadowAttenuation, light.cpp:15-147)
+//   resolve   : per-sample clamp and per-pixel sum (RayTracer.cpp:54,75)
+//   finalize  : mean and 8-bit truncation      (RayTracer.cpp:75,97-99)
+//
+// The recursion of tracePath is unrolled level by level.  A path-tree node returns
+//   (A + 2*pi*B*L1) / (1-q)            without a mirror ray
+//   (A + 2*pi*B*L1 + L2) / (2*(1-q))   with one
+// which is affine in the child radiances L1, L2, so every edge of the tree carries a
+// throughput T and every node adds T*A/norm to its sample's accumulator.  The
+// per-sample clamp (RayTracer.cpp:54) is applied by `resolve` once the whole tree of
+// the sample has been summed.
+#include "kernels.h"
+
+#include <hip/hip_runtime.h>
+
+namespace mipt {
+
+constexpr int kBlock = 256;
+
+// ------------------------------------------------------------------ helpers ----
+__device__ __forceinline__ uint32_t lane_id() { return __lane_id(); }
+
+// Wave-aggregated append: every lane of the wave must call it.
+__device__ __forceinline__ uint32_t wave_append(bool active, uint32_t *counter) {
+  unsigned long long mask = __ballot(active);
+  uint32_t lane = lane_id();
+  uint32_t base = 0;
+  if (mask != 0ull) {
+    int leader = __ffsll((long long)mask) - 1;
+    if ((int)lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(mask));
+    base = __shfl(base, leader);
+  }
+  unsigned long long below = mask & ((1ull << lane) - 1ull);
+  return base + (uint32_t)__popcll(below);
+}
+
+__device__ __forceinline__ void wave_count(unsigned long long *dst, uint32_t v) {
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+  if (lane_id() == 0 && v) atomicAdd(dst, (unsigned long long)v);
+}
+
+__device__ __forceinline__ void deposit(double *accum, uint32_t slot, d3 v) {
+  double *a = accum + 3ull * slot;
+  if (v.x != 0.0) unsafeAtomicAdd(a + 0, v.x);
+  if (v.y != 0.0) unsafeAtomicAdd(a + 1, v.y);
+  if (v.z != 0.0) unsafeAtomicAdd(a + 2, v.z);
+}
+
+__device__ __forceinline__ d3 pow5v(d3 F0, double x) {  // F0 + (1-F0)*x^5, material.cpp:75-78
+  double x2 = x * x;
+  double x5 = x2 * x2 * x;
+  return d3{F0.x + (1.0 - F0.x) * x5, F0.y + (1.0 - F0.y) * x5, F0.z + (1.0 - F0.z) * x5};
+}
+__device__ __forceinline__ double ggx_geometry(d3 n, d3 x, double alpha) {  // material.cpp:68-73
+  double nDotX = fabs(dot(n, x));
+  double denom = nDotX + sqrt((alpha * alpha) + (1 - (alpha * alpha)) * (nDotX * nDotX));
+  return (2 * nDotX) / denom;
+}
+__device__ __forceinline__ double ndf(double alpha, d3 N, d3 H) {  // material.cpp:80-86
+  double a2 = alpha * alpha;
+  double nDotH = fabs(dot(N, H));
+  double inner = (nDotH * nDotH) * (a2 - 1) + 1;
+  return a2 / ((inner * inner) * M_PI);
+}
+
+__device__ __forceinline__ d3 light_direction(const LightRec &L, d3 P) {  // light.cpp:39-41,55-57,96-98
+  if (L.type == MIPT_LIGHT_DIRECTIONAL) return -ld3(L.orientation);
+  if (L.type == MIPT_LIGHT_POINT) return normalize(ld3(L.position) - P);
+  return normalize(ld3(L.center) - P);
+}
+__device__ __forceinline__ double distance_attenuation(const LightRec &L, d3 P) {  // light.cpp:10-13,47-51,88-90
+  if (L.type != MIPT_LIGHT_POINT) return 1.0;
+  double d = length(P - ld3(L.position));
+  double denom = L.a + L.b * d + L.c * (d * d);
+  return fmin(1.0, 1 / denom);
+}
+
+// TextureMap::getPixelAt / getMappedValue, material.cpp:186-222.
+__device__ __forceinline__ d3 tex_pixel(const uint8_t *data, int w, int h, int x, int y) {
+  if (x < 0 || x >= w || y < 0 || y >= h) return d3{0, 0, 0};
+  const uint8_t *p = data + ((size_t)x + (size_t)y * w) * 3;
+  return d3{(double)p[0] / 255.0, (double)p[1] / 255.0, (double)p[2] / 255.0};
+}
+__device__ __forceinline__ d3 tex_mapped(const uint8_t *data, int w, int h, double cu, double cv) {
+  double x = cu * (double)(w - 1), y = cv * (double)(h - 1);
+  double x1 = (double)(int)x, y1 = (double)(int)y;
+  double x2 = x1 + 1, y2 = y1 + 1;
+  d3 c11 = tex_pixel(data, w, h, (int)x1, (int)y1);
+  d3 c12 = tex_pixel(data, w, h, (int)x1, (int)y2);
+  d3 c21 = tex_pixel(data, w, h, (int)x2, (int)y1);
+  d3 c22 = tex_pixel(data, w, h, (int)x2, (int)y2);
+  return ((c11 * (x2 - x) * (y2 - y) + c21 * (x - x1) * (y2 - y)) + c12 * (x2 - x) * (y - y1)) + c22 * (x - x1) * (y - y1);
+}
+// CubeMap::getColor, cubeMap.cpp:7-64 (independent ifs: the last match wins).
+__device__ __forceinline__ d3 cube_color(const SceneDev &S, d3 dirIn) {
+  d3 dir = normalize(dirIn);
+  double absX = fabs(dir.x), absY = fabs(dir.y), absZ = fabs(dir.z);
+  double maxAxis = 0, u = 0, v = 0;
+  int idx = 0;
+  dir.z *= -1;
+  bool px = dir.x > 0, py = dir.y > 0, pz = dir.z > 0;
+  if (px && absX >= absY && absX >= absZ) { maxAxis = absX; u = -dir.z; v = dir.y; idx = 0; }
+  if (!px && absX >= absY && absX >= absZ) { maxAxis = absX; u = dir.z; v = dir.y; idx = 1; }
+  if (py && absY >= absX && absY >= absZ) { maxAxis = absY; u = dir.x; v = -dir.z; idx = 2; }
+  if (!py && absY >= absX && absY >= absZ) { maxAxis = absY; u = dir.x; v = dir.z; idx = 3; }
+  if (pz && absZ >= absX && absZ >= absY) { maxAxis = absZ; u = dir.x; v = dir.y; idx = 4; }
+  if (!pz && absZ >= absX && absZ >= absY) { maxAxis = absZ; u = -dir.x; v = dir.y; idx = 5; }
+  double cu = 0.5 * (u / maxAxis + 1.0), cv = 0.5 * (v / maxAxis + 1.0);
+  return tex_mapped(S.cube[idx], S.cube_w[idx], S.cube_h[idx], cu, cv);
+}
+
+// ---------------------------------------------------------------- generate ----
+__global__ void __launch_bounds__(kBlock) k_generate(SceneDev S, RenderConst rc, const int *__restrict__ rows, int64_t first_pixel,
+                                                      int n_pixels, int sample0, int n_samples, RayQueue q) {
+  uint32_t idx = blockIdx.x * kBlock + threadIdx.x;
+  uint32_t total = (uint32_t)n_pixels * (uint32_t)n_samples;
+  if (idx >= total) return;
+  uint32_t lp = idx / (uint32_t)n_samples;
+  uint32_t k = idx - lp * (uint32_t)n_samples;
+  int64_t op = first_pixel + lp;
+  int j = rows[op / rc.width];
+  int i = (int)(op % rc.width);
+  // tracePixel: x = i/w, y = j/h (RayTracer.cpp:70-71); rayThrough (camera.cpp:20-29)
+  double x = (double)i / (double)rc.width - 0.5;
+  double y = (double)j / (double)rc.height - 0.5;
+  d3 dir = normalize((ld3(S.camera.look) + x * ld3(S.camera.u)) + y * ld3(S.camera.v));
+  q.ox[idx] = S.camera.eye[0]; q.oy[idx] = S.camera.eye[1]; q.oz[idx] = S.camera.eye[2];
+  q.dx[idx] = dir.x; q.dy[idx] = dir.y; q.dz[idx] = dir.z;
+  q.tx[idx] = 1.0; q.ty[idx] = 1.0; q.tz[idx] = 1.0;
+  q.key[idx] = sample_key(rc.seed, (uint64_t)i + (uint64_t)j * (uint64_t)rc.width, (uint64_t)(sample0 + (int)k));
+  q.slot[idx] = idx;
+}
+
+// --------------------------------------------------------------- intersect ----
+template <bool COUNT>
+__global__ void __launch_bounds__(kBlock) k_intersect(SceneDev S, RenderConst rc, RayQueue q, uint32_t n, double *__restrict__ hit_t,
+                                                       int *__restrict__ hit_prim, DeviceCounters *dc) {
+  extern __shared__ uint32_t lds_stack[];
+  uint32_t idx = blockIdx.x * kBlock + threadIdx.x;
+  TravCounters tc{0, 0};
+  if (idx < n) {
+    d3 o{q.ox[idx], q.oy[idx], q.oz[idx]};
+    d3 d{q.dx[idx], q.dy[idx], q.dz[idx]};
+    Hit h = traverse<false, COUNT>(S, o, d, rc.t_max, lds_stack + threadIdx.x, kBlock, tc);
+    hit_t[idx] = h.t;
+    hit_prim[idx] = h.prim;
+  }
+  if (COUNT) {
+    wave_count(&dc->node_visits, tc.nodes);
+    wave_count(&dc->prim_tests, tc.prims);
+  }
+}
+
+// ------------------------------------------------------------------- shade ----
+template <bool COUNT>
+__global__ void __launch_bounds__(kBlock) k_shade(SceneDev S, RenderConst rc, RayQueue q, uint32_t n, const double *__restrict__ hit_t,
+                                                   const int *__restrict__ hit_prim, int depth, RayQueue nq, ShadeList sl, BatchCounts *bc,
+                                                   double *accum, DeviceCounters *dc) {
+  uint32_t idx = blockIdx.x * kBlock + threadIdx.x;
+  bool live = idx < n;
+  bool emitBounce = false, emitMirror = false, emitShade = false;
+  d3 P{0, 0, 0}, N{0, 0, 0}, W{0, 0, 0}, wdir{0, 0, 0}, rdir{0, 0, 0}, Tb{0, 0, 0}, Tm{0, 0, 0};
+  uint64_t key = 0;
+  uint32_t slot = 0;
+  bool shaded = false;
+  if (live) {
+    int prim = hit_prim[idx];
+    d3 o{q.ox[idx], q.oy[idx], q.oz[idx]};
+    d3 d{q.dx[idx], q.dy[idx], q.dz[idx]};
+    d3 T{q.tx[idx], q.ty[idx], q.tz[idx]};
+    key = q.key[idx];
+    slot = q.slot[idx];
+    if (prim < 0) {
+      // miss branch, RayTracer.cpp:279-304
+      if (S.has_cubemap) deposit(accum, slot, T * cube_color(S, d));
+    } else {
+      double u0 = u01(mix64(key, SLOT_RR));
+      if (!(u0 < rc.rr_q)) {  // RayTracer.cpp:228-231
+        shaded = true;
+        double t = hit_t[idx];
+        N = hit_normal(S, prim, o, d);
+        P = o + t * d;  // r.at(i)
+        const ObjRec *ob = S.objects + (S.prim_info[prim] & 0x3fffffffu);
+        const MatRec *m = S.materials + ob->material;
+        d3 kd = ld3(m->kd);
+        // tangent frame, RayTracer.cpp:236-241
+        d3 Nt;
+        if (fabs(N.x) > fabs(N.y)) Nt = d3{N.z, 0, -N.x} / sqrt(N.x * N.x + N.z * N.z);
+        else Nt = d3{0, -N.z, N.y} / sqrt(N.y * N.y + N.z * N.z);
+        d3 Nb = cross(N, Nt);
+        // hemisphere sample, RayTracer.cpp:244-257 (x and z pass through float)
+        double r1 = u01(mix64(key, SLOT_COS));
+        double sinTheta = sqrt(1 - r1 * r1);
+        double phi = u01(mix64(key, SLOT_PHI)) * 2 * M_PI;
+        double sphi, cphi;
+        sincos(phi, &sphi, &cphi);
+        float xf = (float)(sinTheta * cphi);
+        float zf = (float)(sinTheta * sphi);
+        double rx = (double)xf, rz = (double)zf;
+        wdir = normalize(d3{rx * Nb.x + r1 * N.x + rz * Nt.x, rx * Nb.y + r1 * N.y + rz * Nt.y, rx * Nb.z + r1 * N.z + rz * Nt.z});
+        d3 V = normalize(-d);
+        // shadeBRDF set-up, material.cpp:99-109
+        double roughness = m->roughness;
+        double rB = roughness == 0 ? 0.001 : roughness;
+        double alpha = rB * rB;
+        double f0s = (1.0 - m->index) / (1.0 + m->index);
+        f0s = f0s * f0s;
+        d3 F0{f0s, f0s, f0s};
+        double metallic = m->metallic;
+        if (metallic > 0) F0 = F0 * (1.0 - metallic) + kd * metallic;
+        double nV = dot(N, V);
+        double Gv = ggx_geometry(N, V, alpha);
+        // mirror decision, RayTracer.cpp:268-269 (raw roughness)
+        double u3 = u01(mix64(key, SLOT_MIRROR));
+        bool mirror = roughness < u3;
+        double norm = (1.0 - rc.rr_q) * (mirror ? 2.0 : 1.0);
+        // terms that need no shadow ray: ambient + direct specular, material.cpp:96,132-143
+        d3 A = ld3(m->ka) * ld3(S.ambient);
+        for (int li = 0; li < S.n_lights; li++) {
+          const LightRec &L = S.lights[li];
+          d3 Ld = light_direction(L, P);
+          d3 H = normalize(Ld + V);
+          d3 F = pow5v(F0, 1 - fabs(dot(V, H)));
+          double D = ndf(alpha, N, H);
+          double G = ggx_geometry(N, Ld, alpha) * Gv;
+          double nl = fabs(dot(N, Ld));
+          d3 spec = ((F * D) * G) / (4 * nl * nV);
+          A = A + (spec * nl) * distance_attenuation(L, P);
+        }
+        deposit(accum, slot, (T * A) / norm);
+        // indirect coefficient, material.cpp:146-163: B = kd*|n.w|/pi*(1-m) + F*G*D/(4*|n.w|*(n.V))*|n.w|
+        {
+          d3 H = normalize(wdir + V);
+          d3 F = pow5v(F0, 1 - fabs(dot(V, H)));
+          double D = ndf(alpha, N, H);
+          double G = ggx_geometry(N, wdir, alpha) * Gv;
+          double nl = fabs(dot(N, wdir));
+          d3 B = (kd * nl) / M_PI * (1 - metallic) + (((F * G) * D) / (4 * nl * nV)) * nl;
+          Tb = (T * B) * (2 * M_PI) / norm;  // pdf = 1/(2*pi), RayTracer.cpp:261-263
+        }
+        Tm = T / norm;
+        W = ((T * kd) / M_PI * (1 - metallic)) / norm;
+        bool deeper = depth + 1 < rc.max_depth;
+        emitBounce = deeper;
+        emitMirror = deeper && mirror;
+        rdir = d - N * dot(N, d) * 2.0;  // glm::reflect, RayTracer.cpp:270
+        emitShade = S.n_lights > 0 && (W.x != 0.0 || W.y != 0.0 || W.z != 0.0);
+      }
+    }
+  }
+  // ---- compaction: ballot + one atomic per wave and stream --------------------
+  uint32_t ib = wave_append(emitBounce, &bc->next_rays);
+  uint32_t im = wave_append(emitMirror, &bc->next_rays);
+  uint32_t is = wave_append(emitShade, &bc->shades);
+  if (emitBounce) {
+    if (ib < rc.capacity) {
+      d3 ro = P + wdir * MIPT_RAY_EPSILON;  // RayTracer.cpp:259
+      nq.ox[ib] = ro.x; nq.oy[ib] = ro.y; nq.oz[ib] = ro.z;
+      nq.dx[ib] = wdir.x; nq.dy[ib] = wdir.y; nq.dz[ib] = wdir.z;
+      nq.tx[ib] = Tb.x; nq.ty[ib] = Tb.y; nq.tz[ib] = Tb.z;
+      nq.key[ib] = mix64(key, SLOT_CHILD_BOUNCE);
+      nq.slot[ib] = slot;
+    } else {
+      bc->overflow = 1;
+    }
+  }
+  if (emitMirror) {
+    if (im < rc.capacity) {
+      d3 ro = P + MIPT_RAY_EPSILON * N;  // RayTracer.cpp:271
+      nq.ox[im] = ro.x; nq.oy[im] = ro.y; nq.oz[im] = ro.z;
+      nq.dx[im] = rdir.x; nq.dy[im] = rdir.y; nq.dz[im] = rdir.z;
+      nq.tx[im] = Tm.x; nq.ty[im] = Tm.y; nq.tz[im] = Tm.z;
+      nq.key[im] = mix64(key, SLOT_CHILD_MIRROR);
+      nq.slot[im] = slot;
+    } else {
+      bc->overflow = 1;
+    }
+  }
+  if (emitShade) {
+    if (is < rc.capacity) {
+      sl.px[is] = P.x; sl.py[is] = P.y; sl.pz[is] = P.z;
+      sl.nx[is] = N.x; sl.ny[is] = N.y; sl.nz[is] = N.z;
+      sl.wx[is] = W.x; sl.wy[is] = W.y; sl.wz[is] = W.z;
+      sl.key[is] = key;
+      sl.slot[is] = slot;
+    } else {
+      bc->overflow = 1;
+    }
+  }
+  if (COUNT) wave_count(&dc->shaded_hits, shaded ? 1u : 0u);
+}
+
+// ------------------------------------------------------------------ shadow ----
+// The occluder walk of light.cpp:21-33 / 70-83 / 125-138 for translucent scenes.
+template <bool COUNT>
+__device__ d3 shadow_walk(const SceneDev &S, d3 light, d3 p, d3 d, bool has_target, d3 target, double lightT, double tmax,
+                          uint32_t *stack, int stride, TravCounters &tc) {
+  int mat = -1;
+  Hit h = traverse<false, COUNT>(S, p, d, tmax, stack, stride, tc);
+  double pt = h.t;
+  if (h.prim >= 0) mat = S.objects[S.prim_info[h.prim] & 0x3fffffffu].material;
+  int guard = 0;
+  while (pt < lightT && guard++ < 4096) {
+    d3 entry = p + pt * d;
+    p = p + (pt + MIPT_RAY_EPSILON) * d;
+    h = traverse<false, COUNT>(S, p, d, tmax, stack, stride, tc);
+    pt = h.t;
+    if (h.prim >= 0) mat = S.objects[S.prim_info[h.prim] & 0x3fffffffu].material;
+    d3 exitp = p + pt * d;
+    double dist = length(exitp - entry);
+    d3 kt = mat >= 0 ? ld3(S.materials[mat].kt) : d3{0, 0, 0};
+    light = light * d3{pow(kt.x, dist), pow(kt.y, dist), pow(kt.z, dist)};
+    p = p + (pt + MIPT_RAY_EPSILON) * d;
+    h = traverse<false, COUNT>(S, p, d, tmax, stack, stride, tc);
+    pt = h.t;
+    if (h.prim >= 0) mat = S.objects[S.prim_info[h.prim] & 0x3fffffffu].material;
+    if (has_target) lightT = sqrt(dot(target - p, target - p));
+  }
+  return light;
+}
+
+// One shadow ray of light `L` for the shading point with firePos `fire`:
+// sample `s` of an area light (including its min(1, 1/denom), excluding the 1/S),
+// or the single ray of a point / directional light.
+template <bool COUNT, bool WALK>
+__device__ d3 shadow_ray(const SceneDev &S, const RenderConst &rc, const LightRec &L, int li, int s, d3 fire, uint64_t key,
+                         uint32_t *stack, int stride, TravCounters &tc) {
+  d3 color = ld3(L.color);
+  d3 dir, target{0, 0, 0};
+  double lightT = rc.t_max;
+  bool has_target = true;
+  double scale = 1.0;
+  if (L.type == MIPT_LIGHT_DIRECTIONAL) {  // light.cpp:15-35
+    dir = -ld3(L.orientation);
+    has_target = false;
+  } else if (L.type == MIPT_LIGHT_POINT) {  // light.cpp:63-85
+    target = ld3(L.position);
+    dir = normalize(target - fire);
+    lightT = sqrt(dot(target - fire, target - fire));
+  } else {  // light.cpp:105-147
+    double uI, vI;
+    if (rc.flags & MIPT_FLAG_FIXED_AREA_PATTERN) {
+      uI = L.uL * (((double)s + 0.5) / (double)rc.area_samples);
+      vI = L.vL * radical_inverse2((uint32_t)s);
+    } else {
+      uint64_t sl = SLOT_AREA + 2ull * ((uint64_t)li * (uint64_t)rc.area_samples + (uint64_t)s);
+      uI = L.uL * u01(mix64(key, sl));
+      vI = L.vL * u01(mix64(key, sl + 1));
+    }
+    // samplePoint: corner + uVec*uI + vVec + vI — vVec whole, vI on every component (light.cpp:109)
+    d3 cu = (ld3(L.position) + ld3(L.u) * uI) + ld3(L.v);
+    target = d3{cu.x + vI, cu.y + vI, cu.z + vI};
+    dir = normalize(target - fire);
+    lightT = sqrt(dot(target - fire, target - fire));
+    double dd = length(fire - target);
+    double denom = L.a + L.b * dd + L.c * (dd * dd);
+    scale = fmin(1.0, 1 / denom);
+  }
+  d3 light;
+  if (WALK) {
+    light = shadow_walk<COUNT>(S, color, fire, dir, has_target, target, lightT, rc.t_max, stack, stride, tc);
+  } else {
+    // every kt is 0: the walk multiplies by pow(0, dist > 0) = 0 on the first occluder,
+    // so "any hit closer than the light" decides it
+    double lim = fmin(lightT, rc.t_max);
+    Hit h = traverse<true, COUNT>(S, fire, dir, lim, stack, stride, tc);
+    light = h.prim >= 0 ? d3{0, 0, 0} : color;
+  }
+  return light * scale;
+}
+
+template <bool COUNT, bool WALK>
+__global__ void __launch_bounds__(kBlock) k_shadow(SceneDev S, RenderConst rc, ShadeList sl, uint32_t n_shades, uint64_t first_item,
+                                                    uint64_t n_items, double *accum, DeviceCounters *dc) {
+  extern __shared__ uint32_t lds_stack[];
+  uint64_t w = first_item + (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  TravCounters tc{0, 0};
+  d3 v{0, 0, 0};
+  uint32_t h = 0xffffffffu;
+  uint32_t slot = 0;
+  uint32_t R = (uint32_t)S.rays_per_hit;
+  if (w < first_item + n_items) {
+    h = (uint32_t)(w / R);
+    uint32_t r = (uint32_t)(w - (uint64_t)h * R);
+    // light and sample of ray r: lights own consecutive blocks of rays
+    int li = 0;
+    for (int k = 1; k < S.n_lights; k++)
+      if ((uint32_t)S.lights[k].first_ray <= r) li = k;
+    const LightRec &L = S.lights[li];
+    int s = (int)r - L.first_ray;
+    d3 P{sl.px[h], sl.py[h], sl.pz[h]};
+    d3 N{sl.nx[h], sl.ny[h], sl.nz[h]};
+    d3 Wt{sl.wx[h], sl.wy[h], sl.wz[h]};
+    uint64_t key = sl.key[h];
+    slot = sl.slot[h];
+    d3 fire = P + (N * MIPT_RAY_EPSILON) * 3.0;  // material.cpp:117
+    d3 light = shadow_ray<COUNT, WALK>(S, rc, L, li, s, fire, key, lds_stack + threadIdx.x, kBlock, tc);
+    // diffuse term, material.cpp:123-128: shadow * distAtten(P) * kd * |n.L(P)| / pi * (1 - metallic)
+    double f = distance_attenuation(L, P) * fabs(dot(N, light_direction(L, P)));
+    if (L.type == MIPT_LIGHT_RECT_AREA) f = f / (double)L.samples;  // light.cpp:145
+    v = (light * Wt) * f;
+  }
+  // segmented sum over the lanes that share a hit (they are contiguous)
+  uint32_t lane = lane_id();
+  for (int off = 1; off < 64; off <<= 1) {
+    double ox = __shfl_down(v.x, off), oy = __shfl_down(v.y, off), oz = __shfl_down(v.z, off);
+    uint32_t oh = __shfl_down(h, off);
+    if (lane + off < 64 && oh == h) { v.x += ox; v.y += oy; v.z += oz; }
+  }
+  uint32_t ph = __shfl_up(h, 1);
+  bool head = (lane == 0) || (ph != h);
+  if (head && h != 0xffffffffu) deposit(accum, slot, v);
+  if (COUNT) {
+    wave_count(&dc->node_visits, tc.nodes);
+    wave_count(&dc->prim_tests, tc.prims);
+  }
+}
+
+// ----------------------------------------------------------------- resolve ----
+__global__ void __launch_bounds__(kBlock) k_resolve(RenderConst rc, const double *__restrict__ accum, const int *__restrict__ rows,
+                                                     int64_t first_pixel, int n_pixels, int n_samples, double *d_sum, DeviceCounters *dc) {
+  uint32_t lp = blockIdx.x * kBlock + threadIdx.x;
+  uint32_t nans = 0;
+  if (lp < (uint32_t)n_pixels) {
+    int64_t op = first_pixel + lp;
+    int j = rows[op / rc.width];
+    int i = (int)(op % rc.width);
+    double s[3] = {0, 0, 0};
+    const double *a = accum + 3ull * (uint64_t)lp * (uint64_t)n_samples;
+    for (int k = 0; k < n_samples; k++) {
+      bool nan = false;
+#pragma unroll
+      for (int c = 0; c < 3; c++) {
+        double v = a[3 * k + c];
+        if (v != v) { nan = true; v = 0.0; }
+        v = fmin(fmax(v, 0.0), 1.0);  // glm::clamp, RayTracer.cpp:54
+        s[c] += v;
+      }
+      if (nan) nans++;
+    }
+    double *dst = d_sum + 3ull * ((uint64_t)i + (uint64_t)j * (uint64_t)rc.width);
+    dst[0] += s[0];
+    dst[1] += s[1];
+    dst[2] += s[2];
+  }
+  wave_count(&dc->nan_samples, nans);
+}
+
+__global__ void __launch_bounds__(kBlock) k_finalize(const double *__restrict__ d_sum, int64_t n, int spp, float *rgb_f32, uint8_t *rgb8) {
+  int64_t idx = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (idx >= n) return;
+  double c = d_sum[idx] / (double)spp;  // RayTracer.cpp:75
+  if (rgb_f32) rgb_f32[idx] = (float)c;
+  if (rgb8) rgb8[idx] = (uint8_t)(int)(255.0 * c);  // RayTracer.cpp:97-99
+}
+
+// -------------------------------------------------------------- test hooks ----
+__global__ void __launch_bounds__(kBlock) k_intersect_rays(SceneDev S, int64_t n, const double *__restrict__ org, const double *__restrict__ dir,
+                                                            double t_max, double *t, int *prim, double *normal) {
+  extern __shared__ uint32_t lds_stack[];
+  int64_t idx = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (idx >= n) return;
+  TravCounters tc{0, 0};
+  d3 o{org[3 * idx], org[3 * idx + 1], org[3 * idx + 2]};
+  d3 d{dir[3 * idx], dir[3 * idx + 1], dir[3 * idx + 2]};
+  Hit h = traverse<false, false>(S, o, d, t_max, lds_stack + threadIdx.x, kBlock, tc);
+  t[idx] = h.t;
+  prim[idx] = h.prim >= 0 ? (int)S.ref_order[h.prim] : -1;
+  d3 N{0, 0, 0};
+  if (h.prim >= 0) N = hit_normal(S, h.prim, o, d);
+  normal[3 * idx] = N.x;
+  normal[3 * idx + 1] = N.y;
+  normal[3 * idx + 2] = N.z;
+}
+
+template <bool WALK>
+__global__ void __launch_bounds__(kBlock) k_shadow_attenuation(SceneDev S, RenderConst rc, int li, int64_t n, const double *__restrict__ fire,
+                                                                const uint64_t *__restrict__ key, double *out) {
+  extern __shared__ uint32_t lds_stack[];
+  int64_t idx = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (idx >= n) return;
+  TravCounters tc{0, 0};
+  const LightRec &L = S.lights[li];
+  d3 f{fire[3 * idx], fire[3 * idx + 1], fire[3 * idx + 2]};
+  d3 sum{0, 0, 0};
+  for (int s = 0; s < L.samples; s++) sum = sum + shadow_ray<false, WALK>(S, rc, L, li, s, f, key[idx], lds_stack + threadIdx.x, kBlock, tc);
+  if (L.type == MIPT_LIGHT_RECT_AREA) sum = sum / (double)L.samples;
+  out[3 * idx] = sum.x;
+  out[3 * idx + 1] = sum.y;
+  out[3 * idx + 2] = sum.z;
+}
+
+// ---------------------------------------------------------------- launchers ----
+static inline unsigned grid_for(uint64_t n) { return (unsigned)((n + kBlock - 1) / kBlock); }
+static inline size_t stack_bytes(const SceneDev &S) { return (size_t)S.stack_entries * kBlock * sizeof(uint32_t); }
+
+void launch_generate(const SceneDev &S, const RenderConst &rc, const int *rows, int64_t first_pixel, int n_pixels, int sample0,
+                     int n_samples, RayQueue q, hipStream_t st) {
+  uint64_t total = (uint64_t)n_pixels * (uint64_t)n_samples;
+  if (!total) return;
+  hipLaunchKernelGGL(k_generate, dim3(grid_for(total)), dim3(kBlock), 0, st, S, rc, rows, first_pixel, n_pixels, sample0, n_samples, q);
+}
+
+void launch_intersect(const SceneDev &S, const RenderConst &rc, RayQueue q, uint32_t n, double *hit_t, int *hit_prim, DeviceCounters *dc,
+                      bool count, hipStream_t st) {
+  if (!n) return;
+  if (count)
+    hipLaunchKernelGGL(k_intersect<true>, dim3(grid_for(n)), dim3(kBlock), stack_bytes(S), st, S, rc, q, n, hit_t, hit_prim, dc);
+  else
+    hipLaunchKernelGGL(k_intersect<false>, dim3(grid_for(n)), dim3(kBlock), stack_bytes(S), st, S, rc, q, n, hit_t, hit_prim, dc);
+}
+
+void launch_shade(const SceneDev &S, const RenderConst &rc, RayQueue q, uint32_t n, const double *hit_t, const int *hit_prim, int depth,
+                  RayQueue next, ShadeList sl, BatchCounts *bc, double *accum, DeviceCounters *dc, bool count, hipStream_t st) {
+  if (!n) return;
+  if (count)
+    hipLaunchKernelGGL(k_shade<true>, dim3(grid_for(n)), dim3(kBlock), 0, st, S, rc, q, n, hit_t, hit_prim, depth, next, sl, bc, accum, dc);
+  else
+    hipLaunchKernelGGL(k_shade<false>, dim3(grid_for(n)), dim3(kBlock), 0, st, S, rc, q, n, hit_t, hit_prim, depth, next, sl, bc, accum, dc);
+}
+
+void launch_shadow(const SceneDev &S, const RenderConst &rc, ShadeList sl, uint32_t n_shades, double *accum, DeviceCounters *dc, bool count,
+                   hipStream_t st) {
+  uint64_t items = (uint64_t)n_shades * (uint64_t)S.rays_per_hit;
+  if (!items) return;
+  // launches of at most 2^30 lanes; each starts on a hit boundary (a multiple of
+  // rays_per_hit) so no hit is split across launches
+  uint64_t per = ((1ull << 30) / (uint64_t)S.rays_per_hit) * (uint64_t)S.rays_per_hit;
+  for (uint64_t first = 0; first < items; first += per) {
+    uint64_t cnt = items - first < per ? items - first : per;
+    auto kern = S.translucent ? (count ? k_shadow<true, true> : k_shadow<false, true>) : (count ? k_shadow<true, false> : k_shadow<false, false>);
+    hipLaunchKernelGGL(kern, dim3(grid_for(cnt)), dim3(kBlock), stack_bytes(S), st, S, rc, sl, n_shades, first, cnt, accum, dc);
+  }
+}
+
+void launch_resolve(const RenderConst &rc, const double *accum, const int *rows, int64_t first_pixel, int n_pixels, int n_samples,
+                    double *d_sum, DeviceCounters *dc, hipStream_t st) {
+  if (!n_pixels) return;
+  hipLaunchKernelGGL(k_resolve, dim3(grid_for((uint64_t)n_pixels)), dim3(kBlock), 0, st, rc, accum, rows, first_pixel, n_pixels, n_samples, d_sum, dc);
+}
+
+void launch_finalize(const double *d_sum, int64_t n_pixels, int spp, float *rgb_f32, uint8_t *rgb8, hipStream_t st) {
+  int64_t n = 3 * n_pixels;
+  if (!n) return;
+  hipLaunchKernelGGL(k_finalize, dim3(grid_for((uint64_t)n)), dim3(kBlock), 0, st, d_sum, n, spp, rgb_f32, rgb8);
+}
+
+void launch_intersect_rays(const SceneDev &S, int64_t n, const double *org, const double *dir, double t_max, double *t, int *prim,
+                           double *normal, hipStream_t st) {
+  if (!n) return;
+  hipLaunchKernelGGL(k_intersect_rays, dim3(grid_for((uint64_t)n)), dim3(kBlock), stack_bytes(S), st, S, n, org, dir, t_max, t, prim, normal);
+}
+
+void launch_shadow_attenuation(const SceneDev &S, const RenderConst &rc, int light, int64_t n, const double *fire, const uint64_t *key,
+                               double *out, hipStream_t st) {
+  if (!n) return;
+  auto kern = S.translucent ? k_shadow_attenuation<true> : k_shadow_attenuation<false>;
+  hipLaunchKernelGGL(kern, dim3(grid_for((uint64_t)n)), dim3(kBlock), stack_bytes(S), st, S, rc, light, n, fire, key, out);
+}
+
+}  // namespace mipt

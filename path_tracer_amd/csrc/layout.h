@@ -1,0 +1,104 @@
+// layout.h — device data layout shared by the host-side scene builder and the HIP
+// kernels of libmipt.  Plain structs, no HIP types.
+#ifndef MIPT_LAYOUT_H_
+#define MIPT_LAYOUT_H_
+
+#include <stdint.h>
+
+namespace mipt {
+
+// Primitive kinds (top two bits of PrimInfo).
+enum : uint32_t { KIND_SPHERE = 0, KIND_BOX = 1, KIND_SQUARE = 2, KIND_TRI = 3 };
+
+// One BVH2 node, 64 bytes, fetched as four 16-byte loads.  Child boxes are fp32
+// and rounded outward from the fp64 primitive boxes; they only cull, every
+// accepted primitive is tested in fp64.
+//   child >= 0 : index of an inner node
+//   child <  0 : leaf, ~child = (first << 3) | (count - 1), count in 1..8,
+//                `first` indexes the primitive arrays (stored in leaf order)
+//   an absent child has an inverted box (min > max) and is never entered
+struct alignas(16) Node {
+  float lmin[3], lmax[3];
+  float rmin[3], rmax[3];
+  int32_t left, right;
+  int32_t pad0, pad1;
+};
+static_assert(sizeof(Node) == 64, "Node must be 64 bytes");
+
+// One triangle in world space, 96 bytes (six 16-byte loads):
+//   a  : first vertex
+//   n  : unit geometric normal as the reference delivers it
+//        (normalize(normalMatrix * cross(b-a, c-a)), trimesh.h:145-146, scene.h:92-94)
+//   q1, q2 : dual edge vectors, beta = (P-a).q1, gamma = (P-a).q2 — the inverse Gram
+//        matrix of trimesh.h:152-157 folded into the edges
+struct alignas(16) Tri {
+  double a[3];
+  double n[3];
+  double q1[3];
+  double q2[3];
+};
+static_assert(sizeof(Tri) == 96, "Tri must be 96 bytes");
+
+// Per-vertex normals of one triangle, already multiplied by the object's normal
+// matrix (not normalised): N = normalize(w0*na + w1*nb + w2*nc), trimesh.cpp:154-163.
+struct alignas(8) TriNormals {
+  double na[3], nb[3], nc[3];
+};
+
+// One scene object (file order).  inv = rows 0..2 of the inverse transform,
+// row-major 3x4 (MatrixTransform::globalToLocalCoords, scene.h:80-82); normi =
+// transpose(inverse(mat3(xform))), row-major 3x3 (scene.h:76,92-94).
+struct alignas(8) ObjRec {
+  double inv[12];
+  double normi[9];
+  int32_t kind;
+  int32_t material;
+  int32_t smooth;  // mesh has per-vertex normals
+  int32_t pad;
+};
+
+// Material record as shadeBRDF reads it (material.cpp:88-109).  Scalars already
+// passed through the luminance weights of material.cpp:232-241.
+struct alignas(8) MatRec {
+  double kd[3];
+  double ka[3];
+  double kt[3];
+  double roughness;  // as the mirror test reads it (RayTracer.cpp:269)
+  double metallic;
+  double index;
+};
+
+struct alignas(8) LightRec {
+  int32_t type;
+  int32_t samples;      // shadow rays this light fires per shading point
+  int32_t first_ray;    // offset of its first ray in the per-hit shadow-ray block
+  int32_t pad;
+  double color[3];
+  double position[3];     // point: position; area: corner
+  double orientation[3];  // directional: normalised orientation (light.h:46)
+  double u[3], v[3];
+  double center[3];       // area: light.h:124
+  double uL, vL;
+  double a, b, c;         // attenuation coefficients (float in the reference, widened)
+};
+
+struct CameraRec {
+  double eye[3], look[3], u[3], v[3];
+};
+
+// PrimInfo: kind << 30 | object index (file order).
+static inline uint32_t make_prim_info(uint32_t kind, uint32_t obj) { return (kind << 30) | obj; }
+
+// Counter-based random stream: slot numbers of one path node.
+enum : uint64_t {
+  SLOT_RR = 0,
+  SLOT_COS = 1,
+  SLOT_PHI = 2,
+  SLOT_MIRROR = 3,
+  SLOT_CHILD_BOUNCE = 4,
+  SLOT_CHILD_MIRROR = 5,
+  SLOT_AREA = 16
+};
+
+}  // namespace mipt
+#endif

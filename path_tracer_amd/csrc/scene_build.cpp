@@ -1,0 +1,553 @@
+// scene_build.cpp — host-side scene flattening for libmipt.
+//
+// What it produces (layout.h):
+//  * every primitive of the scene (analytic objects and non-degenerate mesh
+//    triangles) numbered in the order the reference's two BVH levels would visit
+//    it — that number breaks exact ties in t the way the reference's "first
+//    visited wins" rule does (scene/bvh.h:160-185 with strict `<` at :172);
+//  * triangles pre-transformed to world space in fp64;
+//  * one flat binned-SAH BVH2 over all primitives with fp32 child boxes rounded
+//    outward.  The tree shape is ours; only the tie-break order is the reference's.
+#include "scene_build.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <future>
+#include <limits>
+
+namespace mipt {
+namespace {
+
+struct D3 {
+  double x, y, z;
+};
+inline D3 operator-(D3 a, D3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+inline D3 operator+(D3 a, D3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+inline D3 operator*(D3 a, double s) { return {a.x * s, a.y * s, a.z * s}; }
+inline double dot(D3 a, D3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+inline D3 cross(D3 a, D3 b) { return {a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y}; }
+inline double len(D3 a) { return std::sqrt(dot(a, a)); }
+inline D3 unit(D3 a) { return a * (1.0 / std::sqrt(dot(a, a))); }
+
+// Column-major 4x4 as in the ABI: m[4*c + r].
+inline double M(const double *m, int r, int c) { return m[4 * c + r]; }
+
+inline D3 apply_point(const double *m, D3 v) {  // fourth row dropped, scene.h:59-63
+  return {M(m, 0, 0) * v.x + M(m, 0, 1) * v.y + M(m, 0, 2) * v.z + M(m, 0, 3),
+          M(m, 1, 0) * v.x + M(m, 1, 1) * v.y + M(m, 1, 2) * v.z + M(m, 1, 3),
+          M(m, 2, 0) * v.x + M(m, 2, 1) * v.y + M(m, 2, 2) * v.z + M(m, 2, 3)};
+}
+
+// Inverse of a general 4x4 (Gauss-Jordan with partial pivoting, fp64).
+bool invert4(const double *a, double *out) {
+  double w[4][8];
+  for (int r = 0; r < 4; r++)
+    for (int c = 0; c < 4; c++) {
+      w[r][c] = M(a, r, c);
+      w[r][c + 4] = (r == c) ? 1.0 : 0.0;
+    }
+  for (int col = 0; col < 4; col++) {
+    int piv = col;
+    for (int r = col + 1; r < 4; r++)
+      if (std::fabs(w[r][col]) > std::fabs(w[piv][col])) piv = r;
+    if (w[piv][col] == 0.0) return false;
+    if (piv != col)
+      for (int c = 0; c < 8; c++) std::swap(w[piv][c], w[col][c]);
+    double d = 1.0 / w[col][col];
+    for (int c = 0; c < 8; c++) w[col][c] *= d;
+    for (int r = 0; r < 4; r++) {
+      if (r == col) continue;
+      double f = w[r][col];
+      if (f == 0.0) continue;
+      for (int c = 0; c < 8; c++) w[r][c] -= f * w[col][c];
+    }
+  }
+  for (int r = 0; r < 4; r++)
+    for (int c = 0; c < 4; c++) out[4 * c + r] = w[r][c + 4];
+  return true;
+}
+
+// transpose(inverse(upper-left 3x3)), row-major out[3*r + c].
+bool normal_matrix(const double *m, double *out) {
+  double a = M(m, 0, 0), b = M(m, 0, 1), c = M(m, 0, 2);
+  double d = M(m, 1, 0), e = M(m, 1, 1), f = M(m, 1, 2);
+  double g = M(m, 2, 0), h = M(m, 2, 1), i = M(m, 2, 2);
+  double det = a * (e * i - f * h) - b * (d * i - f * g) + c * (d * h - e * g);
+  if (det == 0.0) return false;
+  double k = 1.0 / det;
+  // cofactor matrix / det == transpose(inverse)
+  out[0] = (e * i - f * h) * k; out[1] = (f * g - d * i) * k; out[2] = (d * h - e * g) * k;
+  out[3] = (c * h - b * i) * k; out[4] = (a * i - c * g) * k; out[5] = (b * g - a * h) * k;
+  out[6] = (b * f - c * e) * k; out[7] = (c * d - a * f) * k; out[8] = (a * e - b * d) * k;
+  return true;
+}
+
+inline D3 apply3(const double *n, D3 v) {  // row-major 3x3
+  return {n[0] * v.x + n[1] * v.y + n[2] * v.z, n[3] * v.x + n[4] * v.y + n[5] * v.z, n[6] * v.x + n[7] * v.y + n[8] * v.z};
+}
+
+struct Box6 {
+  double mn[3], mx[3];
+  void reset() {
+    for (int a = 0; a < 3; a++) {
+      mn[a] = std::numeric_limits<double>::infinity();
+      mx[a] = -std::numeric_limits<double>::infinity();
+    }
+  }
+  void grow(D3 p) {
+    mn[0] = std::min(mn[0], p.x); mx[0] = std::max(mx[0], p.x);
+    mn[1] = std::min(mn[1], p.y); mx[1] = std::max(mx[1], p.y);
+    mn[2] = std::min(mn[2], p.z); mx[2] = std::max(mx[2], p.z);
+  }
+  void grow(const Box6 &b) {
+    for (int a = 0; a < 3; a++) {
+      mn[a] = std::min(mn[a], b.mn[a]);
+      mx[a] = std::max(mx[a], b.mx[a]);
+    }
+  }
+  double area() const {
+    double dx = mx[0] - mn[0], dy = mx[1] - mn[1], dz = mx[2] - mn[2];
+    if (dx < 0) return 0;
+    return 2.0 * (dx * dy + dy * dz + dz * dx);
+  }
+};
+
+inline float round_down(double v) {
+  float f = (float)v;
+  if ((double)f > v) f = std::nextafterf(f, -std::numeric_limits<float>::infinity());
+  return f;
+}
+inline float round_up(double v) {
+  float f = (float)v;
+  if ((double)f < v) f = std::nextafterf(f, std::numeric_limits<float>::infinity());
+  return f;
+}
+
+// ------------------------------------------------------------- SAH builder ----
+struct BuildPrim {
+  Box6 box;
+  double c[3];
+  uint32_t id;  // reference-order index
+};
+
+constexpr int kLeafMax = 4;    // preferred leaf size
+constexpr int kLeafHard = 8;   // encoding limit (3 bits)
+constexpr int kBins = 16;
+
+struct Builder {
+  std::vector<BuildPrim> &prims;
+  std::vector<Node> nodes;
+  int max_depth = 0;
+  explicit Builder(std::vector<BuildPrim> &p) : prims(p) {}
+
+  static int32_t leaf_code(size_t first, size_t count) { return ~(int32_t)((first << 3) | (count - 1)); }
+
+  // Builds [b, e); returns the child reference and fills `bounds`.
+  int32_t build(size_t b, size_t e, int depth, Box6 *bounds) {
+    size_t n = e - b;
+    Box6 bb, cb;
+    bb.reset();
+    cb.reset();
+    for (size_t i = b; i < e; i++) {
+      bb.grow(prims[i].box);
+      cb.grow(D3{prims[i].c[0], prims[i].c[1], prims[i].c[2]});
+    }
+    *bounds = bb;
+    if (n <= (size_t)kLeafMax) return leaf_code(b, n);
+
+    // binned SAH over the three axes
+    double bestCost = std::numeric_limits<double>::infinity();
+    int bestAxis = -1, bestSplit = -1;
+    for (int axis = 0; axis < 3; axis++) {
+      double lo = cb.mn[axis], hi = cb.mx[axis];
+      if (!(hi > lo)) continue;
+      double scale = kBins / (hi - lo);
+      Box6 binBox[kBins];
+      size_t binCnt[kBins];
+      for (int k = 0; k < kBins; k++) { binBox[k].reset(); binCnt[k] = 0; }
+      for (size_t i = b; i < e; i++) {
+        int k = (int)((prims[i].c[axis] - lo) * scale);
+        if (k < 0) k = 0;
+        if (k >= kBins) k = kBins - 1;
+        binBox[k].grow(prims[i].box);
+        binCnt[k]++;
+      }
+      double rightArea[kBins];
+      size_t rightCnt[kBins];
+      Box6 acc;
+      acc.reset();
+      size_t cnt = 0;
+      for (int k = kBins - 1; k >= 1; k--) {
+        acc.grow(binBox[k]);
+        cnt += binCnt[k];
+        rightArea[k] = acc.area();
+        rightCnt[k] = cnt;
+      }
+      acc.reset();
+      cnt = 0;
+      for (int k = 0; k < kBins - 1; k++) {
+        acc.grow(binBox[k]);
+        cnt += binCnt[k];
+        if (cnt == 0 || rightCnt[k + 1] == 0) continue;
+        double cost = acc.area() * (double)cnt + rightArea[k + 1] * (double)rightCnt[k + 1];
+        if (cost < bestCost) { bestCost = cost; bestAxis = axis; bestSplit = k; }
+      }
+    }
+    size_t mid;
+    if (bestAxis < 0) {
+      // all centroids coincide: split by position in the array
+      if (n <= (size_t)kLeafHard) return leaf_code(b, n);
+      mid = b + n / 2;
+    } else {
+      double leafCost = bb.area() * (double)n;
+      if (n <= (size_t)kLeafHard && leafCost <= 0.125 * bb.area() + bestCost) return leaf_code(b, n);
+      double lo = cb.mn[bestAxis], hi = cb.mx[bestAxis];
+      double scale = kBins / (hi - lo);
+      auto it = std::partition(prims.begin() + b, prims.begin() + e, [&](const BuildPrim &p) {
+        int k = (int)((p.c[bestAxis] - lo) * scale);
+        if (k < 0) k = 0;
+        if (k >= kBins) k = kBins - 1;
+        return k <= bestSplit;
+      });
+      mid = (size_t)(it - prims.begin());
+      if (mid == b || mid == e) mid = b + n / 2;
+    }
+    int32_t me = (int32_t)nodes.size();
+    nodes.emplace_back();
+    max_depth = std::max(max_depth, depth + 1);
+    Box6 lb, rb;
+    int32_t l = build(b, mid, depth + 1, &lb);
+    int32_t r = build(mid, e, depth + 1, &rb);
+    Node &nd = nodes[(size_t)me];
+    for (int a = 0; a < 3; a++) {
+      nd.lmin[a] = round_down(lb.mn[a]); nd.lmax[a] = round_up(lb.mx[a]);
+      nd.rmin[a] = round_down(rb.mn[a]); nd.rmax[a] = round_up(rb.mx[a]);
+    }
+    nd.left = l;
+    nd.right = r;
+    nd.pad0 = nd.pad1 = 0;
+    return me;
+  }
+};
+
+}  // namespace
+
+void reference_visit_order(const std::vector<double> &boxes, std::vector<uint32_t> *order_out) {
+  size_t n = boxes.size() / 6;
+  std::vector<uint32_t> &order = *order_out;
+  order.resize(n);
+  for (size_t i = 0; i < n; i++) order[i] = (uint32_t)i;
+  if (n == 0) return;
+  struct Range { size_t begin, amt; };
+  std::vector<Range> todo;
+  todo.push_back({0, n});
+  auto bmin = [&](size_t k, int a) { return boxes[6 * (size_t)order[k] + a]; };
+  auto bmax = [&](size_t k, int a) { return boxes[6 * (size_t)order[k] + 3 + a]; };
+  while (!todo.empty()) {
+    Range rg = todo.back();
+    todo.pop_back();
+    if (rg.amt <= 2) continue;  // bvh.h:49-52
+    size_t begin = rg.begin, end = rg.begin + rg.amt - 1;
+    double mn[3], mx[3];
+    for (int a = 0; a < 3; a++) { mn[a] = bmin(begin, a); mx[a] = bmax(begin, a); }
+    for (size_t k = begin + 1; k <= end; k++)
+      for (int a = 0; a < 3; a++) {
+        if (bmin(k, a) < mn[a]) mn[a] = bmin(k, a);
+        if (bmax(k, a) > mx[a]) mx[a] = bmax(k, a);
+      }
+    double lengths[3] = {mx[0] - mn[0], mx[1] - mn[1], mx[2] - mn[2]};
+    int axis = 0;  // bvh.h:58-64
+    if (lengths[1] > lengths[axis]) axis = 1;
+    if (lengths[2] > lengths[axis]) axis = 2;
+    double half = lengths[axis] / 2 + mn[axis];  // bvh.h:66
+    // two-pointer partition, bvh.h:67-80 (signed indices: j may pass below begin)
+    int64_t i = (int64_t)begin, j = (int64_t)end;
+    while (i <= j) {
+      double mid = (bmin((size_t)i, axis) + bmax((size_t)i, axis)) / 2;
+      if (mid >= half) {
+        std::swap(order[(size_t)i], order[(size_t)j]);
+        j--;
+      } else {
+        i++;
+      }
+    }
+    size_t leftCount = (size_t)i - begin;
+    if (leftCount == 0 || leftCount == rg.amt) continue;  // bvh.h:97-100: stays one leaf
+    todo.push_back({begin, leftCount});
+    todo.push_back({(size_t)i, rg.amt - leftCount});
+  }
+}
+
+int build_host_scene(const mipt_scene_desc *d, HostScene *out, std::string *err) {
+  HostScene &S = *out;
+  S = HostScene();
+  auto fail = [&](int code, const char *msg) { *err = msg; return code; };
+  if (!d) return fail(MIPT_ERR_INVALID, "null scene description");
+  if (d->n_objects < 0 || d->n_materials < 0 || d->n_meshes < 0 || d->n_lights < 0)
+    return fail(MIPT_ERR_INVALID, "negative count in scene description");
+  if ((d->n_objects && !d->objects) || (d->n_materials && !d->materials) || (d->n_meshes && !d->meshes) || (d->n_lights && !d->lights))
+    return fail(MIPT_ERR_INVALID, "null array in scene description");
+  if (d->n_objects >= (1 << 30)) return fail(MIPT_ERR_LIMIT, "too many objects (limit 2^30-1)");
+
+  std::memcpy(S.camera.eye, d->camera.eye, sizeof(double) * 3);
+  std::memcpy(S.camera.look, d->camera.look, sizeof(double) * 3);
+  std::memcpy(S.camera.u, d->camera.u, sizeof(double) * 3);
+  std::memcpy(S.camera.v, d->camera.v, sizeof(double) * 3);
+  std::memcpy(S.ambient, d->ambient, sizeof(double) * 3);
+
+  auto lum = [](double v) { return (0.299 * v) + (0.587 * v) + (0.114 * v); };  // material.cpp:240
+  for (int k = 0; k < d->n_materials; k++) {
+    const mipt_material &m = d->materials[k];
+    MatRec r;
+    for (int a = 0; a < 3; a++) { r.kd[a] = m.kd[a]; r.ka[a] = m.ka[a]; r.kt[a] = m.kt[a]; }
+    r.roughness = lum(m.roughness);
+    r.metallic = lum(m.metallic);
+    r.index = lum(m.index);
+    if (m.kt[0] != 0.0 || m.kt[1] != 0.0 || m.kt[2] != 0.0) S.translucent = true;
+    S.materials.push_back(r);
+  }
+
+  // ---- lights --------------------------------------------------------------
+  for (int k = 0; k < d->n_lights; k++) {
+    const mipt_light &src = d->lights[k];
+    if (src.type < MIPT_LIGHT_DIRECTIONAL || src.type > MIPT_LIGHT_RECT_AREA) return fail(MIPT_ERR_INVALID, "unknown light type");
+    LightRec L;
+    std::memset(&L, 0, sizeof(L));
+    L.type = src.type;
+    for (int a = 0; a < 3; a++) {
+      L.color[a] = src.color[a];
+      L.position[a] = src.position[a];
+      L.u[a] = src.u[a];
+      L.v[a] = src.v[a];
+    }
+    if (src.type == MIPT_LIGHT_DIRECTIONAL) {
+      D3 o = unit(D3{src.direction[0], src.direction[1], src.direction[2]});  // light.h:46
+      L.orientation[0] = o.x; L.orientation[1] = o.y; L.orientation[2] = o.z;
+    }
+    L.uL = src.uL;
+    L.vL = src.vL;
+    for (int a = 0; a < 3; a++)  // light.h:124: uL/2*uVec + vL/2*vVec + corner
+      L.center[a] = (src.uL / 2 * src.u[a] + src.vL / 2 * src.v[a]) + src.position[a];
+    L.a = (double)src.atten[0];
+    L.b = (double)src.atten[1];
+    L.c = (double)src.atten[2];
+    S.lights.push_back(L);
+  }
+
+  // ---- objects: transforms and world boxes (scene.cpp:54-92) ---------------
+  size_t nObj = (size_t)d->n_objects;
+  std::vector<double> objBoxes(6 * nObj);
+  S.objects.resize(nObj);
+  for (size_t k = 0; k < nObj; k++) {
+    const mipt_object &src = d->objects[k];
+    if (src.type < MIPT_OBJ_SPHERE || src.type > MIPT_OBJ_TRIMESH) return fail(MIPT_ERR_INVALID, "unknown object type");
+    if (src.material < 0 || src.material >= d->n_materials) return fail(MIPT_ERR_INVALID, "object material index out of range");
+    if (src.type == MIPT_OBJ_TRIMESH && (src.mesh < 0 || src.mesh >= d->n_meshes)) return fail(MIPT_ERR_INVALID, "object mesh index out of range");
+    ObjRec &o = S.objects[k];
+    std::memset(&o, 0, sizeof(o));
+    double inv[16];
+    if (!invert4(src.xform, inv)) return fail(MIPT_ERR_INVALID, "singular object transform");
+    for (int r = 0; r < 3; r++)
+      for (int c = 0; c < 4; c++) o.inv[4 * r + c] = M(inv, r, c);
+    if (!normal_matrix(src.xform, o.normi)) return fail(MIPT_ERR_INVALID, "singular object transform");
+    o.kind = src.type;
+    o.material = src.material;
+    D3 mn{0, 0, 0}, mx{0, 0, 0};
+    bool have = true;
+    if (src.type == MIPT_OBJ_SPHERE) { mn = {-1, -1, -1}; mx = {1, 1, 1}; }            // Sphere.h:13-18
+    else if (src.type == MIPT_OBJ_BOX) { mn = {-0.5, -0.5, -0.5}; mx = {0.5, 0.5, 0.5}; }  // Box.h:13-18
+    else if (src.type == MIPT_OBJ_SQUARE) { mn = {-0.5, -0.5, -1e-8}; mx = {0.5, 0.5, 1e-8}; }  // Square.h:13-18
+    else {
+      const mipt_mesh &m = d->meshes[src.mesh];
+      if (m.n_vertices < 0 || m.n_faces < 0 || (m.n_vertices && !m.vertices) || (m.n_faces && !m.faces))
+        return fail(MIPT_ERR_INVALID, "bad mesh arrays");
+      o.smooth = m.normals ? 1 : 0;
+      if (m.n_vertices == 0) have = false;
+      else {
+        mn = mx = D3{m.vertices[0], m.vertices[1], m.vertices[2]};  // trimesh.h:75-90
+        for (int64_t v = 0; v < m.n_vertices; v++) {
+          D3 p{m.vertices[3 * v], m.vertices[3 * v + 1], m.vertices[3 * v + 2]};
+          mn = {std::min(mn.x, p.x), std::min(mn.y, p.y), std::min(mn.z, p.z)};
+          mx = {std::max(mx.x, p.x), std::max(mx.y, p.y), std::max(mx.z, p.z)};
+        }
+      }
+    }
+    Box6 wb;
+    wb.reset();
+    if (have) {
+      for (int corner = 0; corner < 8; corner++) {
+        D3 p{(corner & 1) ? mx.x : mn.x, (corner & 2) ? mx.y : mn.y, (corner & 4) ? mx.z : mn.z};
+        wb.grow(apply_point(src.xform, p));
+      }
+    } else {
+      // an empty mesh has an empty box in the reference; it can never be hit
+      for (int a = 0; a < 3; a++) { wb.mn[a] = 0; wb.mx[a] = 0; }
+    }
+    for (int a = 0; a < 3; a++) { objBoxes[6 * k + a] = wb.mn[a]; objBoxes[6 * k + 3 + a] = wb.mx[a]; }
+  }
+
+  // ---- reference visiting order: objects, then faces inside each mesh --------
+  std::vector<uint32_t> objOrder;
+  reference_visit_order(objBoxes, &objOrder);
+
+  std::vector<BuildPrim> prims;
+  std::vector<Tri> trisRef;          // by reference-order index
+  std::vector<TriNormals> normsRef;  // by reference-order index (if any smooth mesh)
+  std::vector<uint32_t> infoRef;
+  bool anySmooth = false;
+  for (size_t k = 0; k < nObj; k++)
+    if (S.objects[k].smooth) anySmooth = true;
+
+  for (size_t ord = 0; ord < nObj; ord++) {
+    uint32_t oi = objOrder[ord];
+    const mipt_object &src = d->objects[oi];
+    const ObjRec &o = S.objects[oi];
+    if (src.type != MIPT_OBJ_TRIMESH) {
+      BuildPrim bp;
+      for (int a = 0; a < 3; a++) {
+        bp.box.mn[a] = objBoxes[6 * (size_t)oi + a];
+        bp.box.mx[a] = objBoxes[6 * (size_t)oi + 3 + a];
+        bp.c[a] = 0.5 * (bp.box.mn[a] + bp.box.mx[a]);
+      }
+      bp.id = (uint32_t)prims.size();
+      prims.push_back(bp);
+      Tri t;
+      std::memset(&t, 0, sizeof(t));
+      trisRef.push_back(t);
+      if (anySmooth) { TriNormals tn; std::memset(&tn, 0, sizeof(tn)); normsRef.push_back(tn); }
+      infoRef.push_back(make_prim_info((uint32_t)src.type, oi));
+      continue;
+    }
+    const mipt_mesh &m = d->meshes[src.mesh];
+    // non-degenerate faces in addFace order (trimesh.cpp:32-46, trimesh.h:139-141)
+    std::vector<int64_t> faces;
+    std::vector<double> fboxes;
+    faces.reserve((size_t)m.n_faces);
+    for (int64_t f = 0; f < m.n_faces; f++) {
+      int ia = m.faces[3 * f], ib = m.faces[3 * f + 1], ic = m.faces[3 * f + 2];
+      if (ia < 0 || ib < 0 || ic < 0 || ia >= m.n_vertices || ib >= m.n_vertices || ic >= m.n_vertices)
+        return fail(MIPT_ERR_INVALID, "mesh face index out of range");
+      D3 A{m.vertices[3 * ia], m.vertices[3 * ia + 1], m.vertices[3 * ia + 2]};
+      D3 B{m.vertices[3 * ib], m.vertices[3 * ib + 1], m.vertices[3 * ib + 2]};
+      D3 Cc{m.vertices[3 * ic], m.vertices[3 * ic + 1], m.vertices[3 * ic + 2]};
+      if (len(B - A) == 0.0 || len(Cc - A) == 0.0 || len(B - Cc) == 0.0) continue;
+      faces.push_back(f);
+      // local face box, trimesh.h:175-188
+      fboxes.push_back(std::min(Cc.x, std::min(A.x, B.x)));
+      fboxes.push_back(std::min(Cc.y, std::min(A.y, B.y)));
+      fboxes.push_back(std::min(Cc.z, std::min(A.z, B.z)));
+      fboxes.push_back(std::max(Cc.x, std::max(A.x, B.x)));
+      fboxes.push_back(std::max(Cc.y, std::max(A.y, B.y)));
+      fboxes.push_back(std::max(Cc.z, std::max(A.z, B.z)));
+    }
+    std::vector<uint32_t> fOrder;
+    reference_visit_order(fboxes, &fOrder);
+    if (prims.size() + faces.size() >= ((size_t)1 << 28)) return fail(MIPT_ERR_LIMIT, "too many primitives (limit 2^28-1)");
+    for (size_t q = 0; q < fOrder.size(); q++) {
+      int64_t f = faces[fOrder[q]];
+      int ia = m.faces[3 * f], ib = m.faces[3 * f + 1], ic = m.faces[3 * f + 2];
+      D3 A{m.vertices[3 * ia], m.vertices[3 * ia + 1], m.vertices[3 * ia + 2]};
+      D3 B{m.vertices[3 * ib], m.vertices[3 * ib + 1], m.vertices[3 * ib + 2]};
+      D3 Cc{m.vertices[3 * ic], m.vertices[3 * ic + 1], m.vertices[3 * ic + 2]};
+      D3 nLocal = unit(cross(B - A, Cc - A));           // trimesh.h:145-146
+      D3 nWorld = unit(apply3(o.normi, nLocal));        // scene.h:92-94
+      D3 a = apply_point(src.xform, A), b = apply_point(src.xform, B), c = apply_point(src.xform, Cc);
+      D3 e1 = b - a, e2 = c - a;
+      double g11 = dot(e1, e1), g12 = dot(e1, e2), g22 = dot(e2, e2);
+      double ood = 1.0 / (g11 * g22 - g12 * g12);       // trimesh.h:152-157 in world space
+      double A00 = g22 * ood, A01 = -g12 * ood, A11 = g11 * ood;
+      D3 q1 = e1 * A00 + e2 * A01;
+      D3 q2 = e1 * A01 + e2 * A11;
+      Tri t;
+      t.a[0] = a.x; t.a[1] = a.y; t.a[2] = a.z;
+      t.n[0] = nWorld.x; t.n[1] = nWorld.y; t.n[2] = nWorld.z;
+      t.q1[0] = q1.x; t.q1[1] = q1.y; t.q1[2] = q1.z;
+      t.q2[0] = q2.x; t.q2[1] = q2.y; t.q2[2] = q2.z;
+      BuildPrim bp;
+      bp.box.reset();
+      bp.box.grow(a); bp.box.grow(b); bp.box.grow(c);
+      for (int ax = 0; ax < 3; ax++) bp.c[ax] = 0.5 * (bp.box.mn[ax] + bp.box.mx[ax]);
+      bp.id = (uint32_t)prims.size();
+      prims.push_back(bp);
+      trisRef.push_back(t);
+      if (anySmooth) {
+        TriNormals tn;
+        std::memset(&tn, 0, sizeof(tn));
+        if (m.normals) {
+          D3 na = apply3(o.normi, D3{m.normals[3 * ia], m.normals[3 * ia + 1], m.normals[3 * ia + 2]});
+          D3 nb = apply3(o.normi, D3{m.normals[3 * ib], m.normals[3 * ib + 1], m.normals[3 * ib + 2]});
+          D3 nc = apply3(o.normi, D3{m.normals[3 * ic], m.normals[3 * ic + 1], m.normals[3 * ic + 2]});
+          tn.na[0] = na.x; tn.na[1] = na.y; tn.na[2] = na.z;
+          tn.nb[0] = nb.x; tn.nb[1] = nb.y; tn.nb[2] = nb.z;
+          tn.nc[0] = nc.x; tn.nc[1] = nc.y; tn.nc[2] = nc.z;
+        }
+        normsRef.push_back(tn);
+      }
+      infoRef.push_back(make_prim_info(KIND_TRI, oi));
+    }
+  }
+
+  // ---- BVH over all primitives ---------------------------------------------------
+  size_t nPrims = prims.size();
+  Builder builder(prims);
+  builder.nodes.reserve(nPrims / 2 + 16);
+  Box6 rootBox;
+  rootBox.reset();
+  if (nPrims == 0) {
+    Node nd;
+    std::memset(&nd, 0, sizeof(nd));
+    for (int a = 0; a < 3; a++) { nd.lmin[a] = nd.rmin[a] = 1.0f; nd.lmax[a] = nd.rmax[a] = -1.0f; }
+    nd.left = nd.right = ~0;
+    builder.nodes.push_back(nd);
+    builder.max_depth = 1;
+  } else {
+    int32_t root = builder.build(0, nPrims, 0, &rootBox);
+    if (root < 0) {
+      // the whole scene fits one leaf: wrap it in a root node with an absent right child
+      Node nd;
+      std::memset(&nd, 0, sizeof(nd));
+      for (int a = 0; a < 3; a++) {
+        nd.lmin[a] = round_down(rootBox.mn[a]);
+        nd.lmax[a] = round_up(rootBox.mx[a]);
+        nd.rmin[a] = 1.0f;
+        nd.rmax[a] = -1.0f;
+      }
+      nd.left = root;
+      nd.right = ~0;
+      builder.nodes.push_back(nd);
+      builder.max_depth = 1;
+    }
+  }
+  S.nodes = std::move(builder.nodes);
+  S.max_depth = builder.max_depth;
+  S.tris.resize(nPrims);
+  S.prim_info.resize(nPrims);
+  S.ref_order.resize(nPrims);
+  if (anySmooth) S.tri_normals.resize(nPrims);
+  for (size_t s = 0; s < nPrims; s++) {
+    uint32_t id = prims[s].id;
+    S.tris[s] = trisRef[id];
+    S.prim_info[s] = infoRef[id];
+    S.ref_order[s] = id;
+    if (anySmooth) S.tri_normals[s] = normsRef[id];
+  }
+  double R = 0;
+  if (nPrims)
+    for (int a = 0; a < 3; a++) R = std::max(R, std::max(std::fabs(rootBox.mn[a]), std::fabs(rootBox.mx[a])));
+  S.radius = R;
+
+  if (d->cubemap) {
+    S.has_cubemap = true;
+    for (int f = 0; f < 6; f++) {
+      const mipt_image &im = d->cubemap[f];
+      if (im.width <= 0 || im.height <= 0 || !im.rgb) return fail(MIPT_ERR_INVALID, "bad cubemap face");
+      S.cube_w[f] = im.width;
+      S.cube_h[f] = im.height;
+      S.cube_rgb[f].assign(im.rgb, im.rgb + (size_t)3 * im.width * im.height);
+    }
+  }
+  return MIPT_OK;
+}
+
+}  // namespace mipt

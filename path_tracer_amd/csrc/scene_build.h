@@ -1,0 +1,43 @@
+// scene_build.h — host side of mipt_upload_scene: turns the scene description into
+// the flat arrays the kernels read (see layout.h).
+#ifndef MIPT_SCENE_BUILD_H_
+#define MIPT_SCENE_BUILD_H_
+
+#include <string>
+#include <vector>
+
+#include "../../include/mipt.h"
+#include "layout.h"
+
+namespace mipt {
+
+struct HostScene {
+  CameraRec camera;
+  double ambient[3];
+  std::vector<Node> nodes;             // nodes[0] is the root
+  std::vector<Tri> tris;               // per primitive (leaf order); unused slots for analytic prims
+  std::vector<TriNormals> tri_normals; // per primitive, empty if no mesh has vertex normals
+  std::vector<uint32_t> prim_info;     // kind << 30 | object
+  std::vector<uint32_t> ref_order;     // reference visiting order of each primitive (tie-break key)
+  std::vector<ObjRec> objects;
+  std::vector<MatRec> materials;
+  std::vector<LightRec> lights;
+  int rays_per_hit = 0;                // shadow rays per shaded hit for a given area_samples
+  int max_depth = 0;                   // deepest inner-node nesting (traversal stack bound)
+  double radius = 0;                   // max |coordinate| of the scene bounds
+  bool translucent = false;            // some material has kt != 0
+  bool has_cubemap = false;
+  int cube_w[6], cube_h[6];
+  std::vector<uint8_t> cube_rgb[6];
+};
+
+// Returns MIPT_OK or an error code with `err` set.
+int build_host_scene(const mipt_scene_desc *desc, HostScene *out, std::string *err);
+
+// Replays BVH<T>::makeBVH (scene/bvh.h:40-110) on a list of boxes and returns the
+// final allNodes order: order[k] = index of the k-th item the reference's
+// left-to-right traversal visits.  boxes: 6 doubles per item (min xyz, max xyz).
+void reference_visit_order(const std::vector<double> &boxes, std::vector<uint32_t> *order);
+
+}  // namespace mipt
+#endif
