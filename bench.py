@@ -1,0 +1,292 @@
+#!/usr/bin/env python3
+"""Benchmark of the path-tracing hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One *step* = one pass of the wavefront pipeline (generate -> intersect -> shade ->
+shadow -> ... -> resolve) over `--spp-per-step` samples of every pixel of the frame,
+with scene, queues and the radiance sum resident in HBM.  Metric: path samples/s
+(one path sample = one `trace(x, y)` call of the reference, RayTracer.cpp:38-56:
+a camera ray plus its whole tree of bounce, mirror and shadow rays).
+
+With N > 1 (launched by torch.distributed.run, one rank per GPU) every rank renders
+the whole frame for its own slice of the sample range (weak scaling: per-GPU work is
+fixed) and the per-pixel sums are reduced to rank 0 over RCCL once, inside the timed
+region.
+
+Rank 0 prints one JSON line; see DESIGN.md for how `roofline` and `cpu_baseline`
+are defined.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
+
+WORKLOADS = {
+    # name: (triangles, width, height, area lights, cubemap, nominal spp)
+    "synth1m": (1_000_000, 1920, 1080, 1, False, 4096),
+    "synth10m": (10_000_000, 3840, 2160, 64, True, 8192),
+    "synth100k": (100_000, 1920, 1080, 1, False, 4096),
+}
+FIXTURE_WORKLOADS = {
+    # name: (fixture, width, height, nominal spp)
+    "spheres": ("spheres", 512, 512, 100),
+    "cornell": ("cornellBoxes", 1024, 1024, 1024),
+    "hitchcock": ("hitchcockBRDF", 1920, 1080, 2048),
+}
+
+
+def build_scene(name, triangles=None):
+    from path_tracer_amd import synth
+    from path_tracer_amd.scene import Scene
+
+    if name in WORKLOADS:
+        tris, w, h, nl, cube, spp = WORKLOADS[name]
+        if triangles:
+            tris = triangles
+        sc = synth.make_scene(tris, seed=0xC4 if name != "synth10m" else 0xC5, n_area_lights=nl, cubemap=cube)
+        label = f"synthetic {sc.n_triangles()}-triangle mesh scene, {nl} area light(s) + 1 directional, {w}x{h}"
+        return sc, w, h, spp, label
+    fx, w, h, spp = FIXTURE_WORKLOADS[name]
+    sc = Scene.load_npz(os.path.join(ROOT, "tests", "golden", "scenes", fx + ".npz"))
+    return sc, w, h, spp, f"{fx} (reference demo scene), {w}x{h}"
+
+
+def algorithmic_bytes(c, which):
+    """Layout-independent accounting of the bytes a kernel's work needs: 64 B per BVH2
+    node visit, 48 B per primitive test, 160 B per ray-state record handled by a stage."""
+    if which == "shadow":
+        return 64 * c["shadow_node_visits"] + 48 * c["shadow_prim_tests"] + 160 * c["shaded_records"]
+    if which == "intersect":
+        return 64 * (c["node_visits"] - c["shadow_node_visits"]) + 48 * (c["prim_tests"] - c["shadow_prim_tests"]) + 160 * c["path_rays"]
+    raise KeyError(which)
+
+
+def cpu_baseline(scene, base_params, budget_s=20.0):
+    """Time the CPU oracle (a port of the reference's algorithm, un-pruned two-level BVH,
+    fp64, std::thread column chunks) on a bounded sample of the same workload: every
+    M-th row of the frame at 1 spp, M chosen so the run takes roughly `budget_s`."""
+    import copy
+
+    from oracle.binding import Oracle
+
+    threads = min(16, os.cpu_count() or 1)
+    orc = Oracle(scene)
+    p = copy.copy(base_params)
+    p.spp, p.sample_begin, p.sample_end = 1, 0, 1
+    p.band_rows = 1
+    # calibrate on one row
+    p.shard_count, p.shard_index = p.height, p.height // 3
+    t0 = time.time()
+    orc.render(p, threads=threads)
+    dt = max(time.time() - t0, 1e-3)
+    rows = int(max(1, min(p.height, budget_s / dt)))
+    p.shard_count = max(1, p.height // rows)
+    p.shard_index = 0
+    n_rows = len(range(0, p.height, p.shard_count))
+    t0 = time.time()
+    img = orc.render(p, threads=threads)
+    dt = time.time() - t0
+    samples = n_rows * p.width
+    return {
+        "value": samples / dt / 1e6,
+        "unit": "Msamples/s",
+        "cores": threads,
+        "kind": "port",
+        "sample": f"rows 0, {p.shard_count}, {2 * p.shard_count}, ... ({n_rows} rows x {p.width} px) of the frame at 1 spp, {dt:.1f} s",
+    }, p, img
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="synth1m", choices=sorted(list(WORKLOADS) + list(FIXTURE_WORKLOADS)))
+    ap.add_argument("--spp-per-step", type=int, default=1)
+    ap.add_argument("--triangles", type=int, default=0)
+    ap.add_argument("--batch-samples", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=20.0)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    from path_tracer_amd import abi
+    from path_tracer_amd.dist import combine, shard_params
+    from path_tracer_amd.raytracer import Context
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus} (WORLD_SIZE={world})")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the render path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    scene, w, h, nominal_spp, label = build_scene(args.workload, args.triangles)
+    ctx = Context(local_rank)
+    t0 = time.time()
+    ctx.upload_scene(scene)
+    upload_s = time.time() - t0
+    stats = ctx.scene_stats()
+
+    K, W, S = args.steps, args.warmup, args.spp_per_step
+    total_spp = world * (K + W) * S  # the job the steps are slices of
+    base = abi.default_params(w, h, spp=total_spp, batch_samples=args.batch_samples)
+    d_sum = torch.zeros(3 * w * h, dtype=torch.float64, device=f"cuda:{local_rank}")
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step_params(step, flags):
+        p = shard_params(base, rank, world, "samples")
+        first = p.sample_begin + step * S
+        p.sample_begin, p.sample_end = first, first + S
+        p.flags = flags
+        return p
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    for s in range(W):
+        ctx.render_accumulate(step_params(s, 0), d_sum.data_ptr(), stream)
+    ctx.reset_counters()
+    sync()
+    t0 = time.perf_counter()
+    for s in range(W, W + K):
+        ctx.render_accumulate(step_params(s, abi.FLAG_PROFILE), d_sum.data_ptr(), stream)
+    full = combine(d_sum, base, "samples", dst=0)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ktimes = ctx.kernel_times()
+
+    samples_total = world * K * S * w * h
+    out = None
+    if rank == 0:
+        # one instrumented (untimed) step for the work counters; the work is deterministic
+        ctx.reset_counters()
+        scratch = torch.zeros_like(d_sum)
+        ctx.render_accumulate(step_params(W, abi.FLAG_COUNTERS), scratch.data_ptr(), stream)
+        torch.cuda.synchronize()
+        cnt = ctx.counters()
+        del scratch
+        step_samples = S * w * h
+        cnt["shaded_records"] = cnt["shadow_rays"] // max(1, scene_rays_per_hit(scene, base.area_samples))
+        dominant = max(("intersect", "shadow"), key=lambda k: ktimes[k]["ms"])
+        kt = ktimes[dominant]
+        bytes_step = algorithmic_bytes(cnt, dominant)
+        launches_step = kt["launches"] / K
+        avg_launch_ms = kt["ms"] / max(1, kt["launches"])
+        achieved = (bytes_step / max(1.0, launches_step)) / (avg_launch_ms * 1e-3) / 1e9 if kt["launches"] else 0.0
+        roofline = {
+            "bound": "hbm",
+            "kernel": "k_" + dominant,
+            "achieved": achieved,
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS,
+            "traffic": load_traffic(args.workload, dominant),
+            "avg_launch_ms": avg_launch_ms,
+            "launches_per_step": launches_step,
+            "algorithmic_bytes_per_sample": (algorithmic_bytes(cnt, "intersect") + algorithmic_bytes(cnt, "shadow") + 64 * cnt["shaded_hits"]) / step_samples,
+        }
+        out = {
+            "metric": "path samples/s",
+            "value": samples_total / elapsed / 1e6,
+            "unit": "Msamples/s",
+            "n_gpus": world,
+            "steps": K,
+            "warmup": W,
+            "ms_per_step": elapsed / K * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": label,
+                "spp_per_step": S,
+                "nominal_spp": nominal_spp,
+                "rr_q": base.rr_q,
+                "area_samples": base.area_samples,
+                "max_depth": base.max_depth,
+                "primitives": stats["prims"],
+                "bvh_nodes": stats["nodes"],
+                "scene_bytes": stats["device_bytes"],
+                "sharding": "samples" if world > 1 else "none",
+            },
+            "roofline": roofline,
+            "kernel_ms_per_step": {k: v["ms"] / K for k, v in ktimes.items()},
+            "per_sample": {
+                "path_rays": cnt["path_rays"] / step_samples,
+                "shadow_rays": cnt["shadow_rays"] / step_samples,
+                "shaded_hits": cnt["shaded_hits"] / step_samples,
+                "node_visits": cnt["node_visits"] / step_samples,
+                "prim_tests": cnt["prim_tests"] / step_samples,
+            },
+            "mrays_per_s": (cnt["path_rays"] + cnt["shadow_rays"]) / step_samples * samples_total / elapsed / 1e6,
+            "scene_upload_s": upload_s,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            cb, p_cpu, img_cpu = cpu_baseline(scene, base, args.cpu_budget)
+            out["cpu_baseline"] = cb
+            # the same rows on the GPU, same random streams: parity of the bench workload itself
+            p_gpu = abi.default_params(w, h, spp=1, band_rows=1, shard_count=p_cpu.shard_count, shard_index=0)
+            f32, _ = ctx.render(p_gpu, want_f32=True, want_rgb8=False)
+            rows = np.arange(0, h, p_cpu.shard_count)
+            diff = f32[rows].astype(np.float64) - img_cpu[rows]
+            out["parity"] = {
+                "rmsd": float(np.sqrt(np.mean(diff * diff))),
+                "max_abs": float(np.abs(diff).max()),
+                "pixels_over_1e-5": int((np.abs(diff).max(axis=2) > 1e-5).sum()),
+                "pixels": int(diff.shape[0] * diff.shape[1]),
+            }
+            out["vs_cpu_baseline"] = out["value"] / cb["value"] if cb["value"] > 0 else None
+        print(json.dumps(out), flush=True)
+    ctx.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def scene_rays_per_hit(scene, area_samples):
+    from path_tracer_amd import abi
+
+    return sum(area_samples if L.type == abi.LIGHT_RECT_AREA else 1 for L in scene.lights)
+
+
+def load_traffic(workload, kernel):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC
+    passes (profiles/traffic.json), or None when no measurement for this workload exists."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        with open(path) as fh:
+            t = json.load(fh)
+        return t.get(workload, {}).get("k_" + kernel, {}).get("hbm_bytes_per_launch")
+    except (OSError, ValueError):
+        return None
+
+
+if __name__ == "__main__":
+    main()

@@ -139,6 +139,9 @@ typedef struct mipt_scene_desc {
                                            pattern instead of random points  */
 #define MIPT_FLAG_COUNTERS 2u           /* collect traversal / shading counters
                                            (slower instrumented kernels)     */
+#define MIPT_FLAG_PROFILE 4u            /* bracket every kernel launch with HIP
+                                           events on its stream and accumulate
+                                           the durations (mipt_get_kernel_times) */
 
 /* The literals of the reference are parameters here and default to the
  * reference's values (mipt_default_params):
@@ -152,7 +155,8 @@ typedef struct mipt_params {
   double rr_q;          /* Russian-roulette kill probability; 0 disables it   */
   double t_max;         /* hits at t >= t_max are misses                      */
   int32_t max_depth;    /* rays at depth >= max_depth are not traced (the
-                           reference recursion is unbounded; 64 by default)   */
+                           reference recursion is unbounded); 1..255, 64 by
+                           default                                            */
   uint32_t flags;
   uint64_t seed;
   /* sharding: this call renders rows y with (y / band_rows) % shard_count ==
@@ -162,7 +166,9 @@ typedef struct mipt_params {
   int32_t band_rows;
   int32_t sample_begin;
   int32_t sample_end;
-  int32_t batch_samples; /* path samples per wavefront batch; 0 = default     */
+  int32_t batch_samples; /* path samples per wavefront batch (also the most
+                            rays one kernel launch takes); 0 = default 2^22,
+                            at most 2^24                                       */
 } mipt_params;
 
 /* Work counters (summed over everything rendered since the last reset). */
@@ -171,11 +177,27 @@ typedef struct mipt_counters {
   uint64_t path_rays;    /* camera + bounce + mirror rays traced              */
   uint64_t shadow_rays;  /* shadow rays traced                                */
   uint64_t shaded_hits;  /* tracePath nodes that survived Russian roulette    */
-  uint64_t node_visits;  /* BVH nodes fetched (both kernels)                  */
-  uint64_t prim_tests;   /* primitive intersection tests                      */
+  uint64_t node_visits;  /* BVH nodes fetched, closest-hit + shadow kernels   */
+  uint64_t prim_tests;   /* primitive intersection tests, both kernels        */
+  uint64_t shadow_node_visits; /* the shadow kernel's share of node_visits    */
+  uint64_t shadow_prim_tests;  /* the shadow kernel's share of prim_tests     */
   uint64_t ray_stages;   /* ray-state records read+written by kernel stages   */
   uint64_t nan_samples;  /* samples whose radiance was NaN (counted as 0)     */
 } mipt_counters;
+
+/* Device time per kernel, summed over launches made with MIPT_FLAG_PROFILE since
+ * the last mipt_reset_counters.  Index: MIPT_K_*. */
+#define MIPT_K_GENERATE 0
+#define MIPT_K_INTERSECT 1
+#define MIPT_K_SHADE 2
+#define MIPT_K_SHADOW 3
+#define MIPT_K_RESOLVE 4
+#define MIPT_K_COUNT 5
+typedef struct mipt_kernel_times {
+  double ms[MIPT_K_COUNT];        /* summed HIP-event durations, milliseconds */
+  uint64_t launches[MIPT_K_COUNT];
+  uint64_t items[MIPT_K_COUNT];   /* rays / hits / pixels the launches processed */
+} mipt_kernel_times;
 
 typedef struct mipt_ctx mipt_ctx;
 
@@ -249,6 +271,11 @@ int mipt_shadow_attenuation(mipt_ctx *ctx, const mipt_params *p, int light, int6
 /* Counters since the last reset (filled only by calls with MIPT_FLAG_COUNTERS). */
 int mipt_get_counters(mipt_ctx *ctx, mipt_counters *out);
 int mipt_reset_counters(mipt_ctx *ctx);
+
+/* Per-kernel device time of the launches made with MIPT_FLAG_PROFILE (no
+ * counterpart in the reference, whose only timer is clock() around traceImage,
+ * ui/CommandLineUI.cpp:78-101). */
+int mipt_get_kernel_times(mipt_ctx *ctx, mipt_kernel_times *out);
 
 /* Number of primitives (analytic objects + non-degenerate triangles) and BVH
  * nodes of the uploaded scene, and bytes of device memory they occupy. */

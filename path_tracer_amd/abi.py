@@ -12,6 +12,9 @@ OBJ_SPHERE, OBJ_BOX, OBJ_SQUARE, OBJ_TRIMESH = 0, 1, 2, 3
 LIGHT_DIRECTIONAL, LIGHT_POINT, LIGHT_RECT_AREA = 0, 1, 2
 FLAG_FIXED_AREA_PATTERN = 1
 FLAG_COUNTERS = 2
+FLAG_PROFILE = 4
+K_GENERATE, K_INTERSECT, K_SHADE, K_SHADOW, K_RESOLVE, K_COUNT = 0, 1, 2, 3, 4, 5
+KERNEL_NAMES = ("generate", "intersect", "shade", "shadow", "resolve")
 
 OK, ERR_INVALID, ERR_NOSCENE, ERR_DEVICE, ERR_NOMEM, ERR_LIMIT = 0, -1, -2, -3, -4, -5
 
@@ -118,12 +121,21 @@ class Counters(C.Structure):
         ("shaded_hits", C.c_uint64),
         ("node_visits", C.c_uint64),
         ("prim_tests", C.c_uint64),
+        ("shadow_node_visits", C.c_uint64),
+        ("shadow_prim_tests", C.c_uint64),
         ("ray_stages", C.c_uint64),
         ("nan_samples", C.c_uint64),
     ]
 
     def as_dict(self):
         return {name: int(getattr(self, name)) for name, _ in self._fields_}
+
+
+class KernelTimes(C.Structure):
+    _fields_ = [("ms", C.c_double * 5), ("launches", C.c_uint64 * 5), ("items", C.c_uint64 * 5)]
+
+    def as_dict(self):
+        return {KERNEL_NAMES[k]: {"ms": float(self.ms[k]), "launches": int(self.launches[k]), "items": int(self.items[k])} for k in range(5)}
 
 
 def default_params(width: int, height: int, **over) -> Params:
@@ -174,6 +186,7 @@ SIGNATURES = {
     "mipt_shadow_attenuation": (C.c_int, [C.c_void_p, C.POINTER(Params), C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mipt_get_counters": (C.c_int, [C.c_void_p, C.POINTER(Counters)]),
     "mipt_reset_counters": (C.c_int, [C.c_void_p]),
+    "mipt_get_kernel_times": (C.c_int, [C.c_void_p, C.POINTER(KernelTimes)]),
     "mipt_scene_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
 }
 

@@ -40,7 +40,17 @@ struct mipt_ctx {
   // render workspace
   uint32_t capacity = 0;
   DevBuf queue[2], shade, hits, accum, rows, counts, dcount;
+  DevBuf spill;              // overflow stack of ray records (allocated on first use)
+  uint64_t spill_cap = 0;    // entries
   mipt_counters totals{};
+
+  // MIPT_FLAG_PROFILE: event pairs recorded around kernel launches, resolved after
+  // the stream has been synchronised
+  struct Span { int kind; hipEvent_t a, b; uint64_t items; };
+  std::vector<hipEvent_t> event_pool;
+  size_t events_used = 0;
+  std::vector<Span> spans;
+  mipt_kernel_times ktimes{};
 };
 
 namespace {
@@ -95,6 +105,50 @@ int upload(mipt_ctx *c, const std::vector<T> &v, const T **dst) {
   return MIPT_OK;
 }
 
+hipEvent_t take_event(mipt_ctx *c) {
+  if (c->events_used == c->event_pool.size()) {
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    c->event_pool.push_back(e);
+  }
+  return c->event_pool[c->events_used++];
+}
+
+// Brackets one kernel launch with events on its own stream.
+struct ProfScope {
+  mipt_ctx *c;
+  hipStream_t st;
+  bool on;
+  mipt_ctx::Span span;
+  ProfScope(mipt_ctx *ctx, bool enabled, int kind, uint64_t items, hipStream_t stream) : c(ctx), st(stream), on(enabled) {
+    if (!on) return;
+    span.kind = kind;
+    span.items = items;
+    span.a = take_event(c);
+    span.b = take_event(c);
+    if (!span.a || !span.b) { on = false; return; }
+    (void)hipEventRecord(span.a, st);
+  }
+  ~ProfScope() {
+    if (!on) return;
+    (void)hipEventRecord(span.b, st);
+    c->spans.push_back(span);
+  }
+};
+
+void collect_spans(mipt_ctx *c) {
+  for (const auto &sp : c->spans) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, sp.a, sp.b) == hipSuccess) {
+      c->ktimes.ms[sp.kind] += (double)ms;
+      c->ktimes.launches[sp.kind] += 1;
+      c->ktimes.items[sp.kind] += sp.items;
+    }
+  }
+  c->spans.clear();
+  c->events_used = 0;
+}
+
 void free_scene(mipt_ctx *c) {
   for (void *p : c->scene_allocs) (void)hipFree(p);
   c->scene_allocs.clear();
@@ -132,12 +186,34 @@ int check_params(mipt_ctx *c, const mipt_params *p) {
   if (p->area_samples <= 0 || p->area_samples > 4096) return set_err(c, MIPT_ERR_INVALID, "area_samples must be in 1..4096");
   if (!(p->rr_q >= 0.0 && p->rr_q < 1.0)) return set_err(c, MIPT_ERR_INVALID, "rr_q must be in [0, 1)");
   if (!(p->t_max > 0.0)) return set_err(c, MIPT_ERR_INVALID, "t_max must be positive");
-  if (p->max_depth <= 0 || p->max_depth > 4096) return set_err(c, MIPT_ERR_INVALID, "max_depth must be in 1..4096");
+  if (p->max_depth <= 0 || p->max_depth > 255) return set_err(c, MIPT_ERR_INVALID, "max_depth must be in 1..255");
   if (p->shard_count < 1 || p->shard_index < 0 || p->shard_index >= p->shard_count || p->band_rows < 1)
     return set_err(c, MIPT_ERR_INVALID, "bad shard parameters");
   if (p->sample_begin < 0 || p->sample_end > p->spp || p->sample_begin > p->sample_end)
     return set_err(c, MIPT_ERR_INVALID, "bad sample range");
   if (p->batch_samples < 0) return set_err(c, MIPT_ERR_INVALID, "batch_samples must be >= 0");
+  return MIPT_OK;
+}
+
+// Makes room for `extra` more entries on the overflow stack that holds `used`.
+int ensure_spill(mipt_ctx *c, uint64_t used, uint64_t extra, hipStream_t st) {
+  uint64_t need = used + extra;
+  if (need <= c->spill_cap) return MIPT_OK;
+  uint64_t cap = std::max<uint64_t>(2 * need, 1u << 20);
+  if (cap > 0x7fffff00ull || cap * kEntryBytes > (64ull << 30))
+    return set_err(c, MIPT_ERR_LIMIT,
+                   "path tree outgrew the overflow stack (%llu rays): the scene multiplies rays faster than they die; lower max_depth",
+                   (unsigned long long)need);
+  void *np = nullptr;
+  HIP_TRY(c, hipMalloc(&np, cap * kEntryBytes + 64));
+  if (used) {
+    launch_copy_rays(carve_queue(c->spill.p, (uint32_t)c->spill_cap), 0, carve_queue(np, (uint32_t)cap), 0, (uint32_t)used, st);
+    HIP_TRY(c, hipStreamSynchronize(st));
+  }
+  if (c->spill.p) HIP_TRY(c, hipFree(c->spill.p));
+  c->spill.p = np;
+  c->spill.bytes = cap * kEntryBytes + 64;
+  c->spill_cap = cap;
   return MIPT_OK;
 }
 
@@ -227,6 +303,8 @@ void mipt_destroy(mipt_ctx *c) {
   release(c->rows);
   release(c->counts);
   release(c->dcount);
+  release(c->spill);
+  for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
   delete c;
 }
 
@@ -301,6 +379,7 @@ int mipt_render_accumulate(mipt_ctx *c, const mipt_params *p, double *d_sum, voi
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if ((r = sync_lights(c, p->area_samples)) != MIPT_OK) return r;
   bool count = (p->flags & MIPT_FLAG_COUNTERS) != 0;
+  bool prof = (p->flags & MIPT_FLAG_PROFILE) != 0;
 
   // rows owned by this shard
   std::vector<int> rows;
@@ -316,7 +395,7 @@ int mipt_render_accumulate(mipt_ctx *c, const mipt_params *p, double *d_sum, voi
   int64_t PB = std::max<int64_t>(1, B / SB);
   PB = std::min<int64_t>(PB, owned);
   int64_t batch = PB * SB;
-  if (2 * batch + 1024 > 0x7fffffffll) return set_err(c, MIPT_ERR_LIMIT, "batch_samples too large");
+  if (batch > (1ll << 24)) return set_err(c, MIPT_ERR_LIMIT, "batch_samples too large (limit 2^24)");
   uint32_t cap = (uint32_t)(2 * batch + 1024);
   c->capacity = cap;
   if ((r = ensure(c, c->queue[0], (size_t)cap * kEntryBytes + 64)) != MIPT_OK) return r;
@@ -350,33 +429,63 @@ int mipt_render_accumulate(mipt_ctx *c, const mipt_params *p, double *d_sum, voi
       int ns = std::min(SB, p->sample_end - s0);
       uint32_t n = (uint32_t)((int64_t)npix * ns);
       HIP_TRY(c, hipMemsetAsync(accum, 0, (size_t)n * 3 * sizeof(double), st));
-      launch_generate(c->dev, rc, d_rows, p0, npix, s0, ns, q[0], st);
+      {
+        ProfScope ps(c, prof, MIPT_K_GENERATE, n, st);
+        launch_generate(c->dev, rc, d_rows, p0, npix, s0, ns, q[0], st);
+      }
       if (count) { tot.samples += n; tot.ray_stages += n; }
       int cur = 0;
-      for (int depth = 0; n > 0 && depth < p->max_depth; depth++) {
+      uint64_t spilled = 0;  // entries on the overflow stack
+      const uint32_t chunk = (uint32_t)batch;  // rays per launch; children of one launch always fit a queue
+      while (n > 0) {
         HIP_TRY(c, hipMemsetAsync(bc, 0, sizeof(BatchCounts), st));
-        launch_intersect(c->dev, rc, q[cur], n, hit_t, hit_prim, dc, count, st);
-        launch_shade(c->dev, rc, q[cur], n, hit_t, hit_prim, depth, q[cur ^ 1], sl, bc, accum, dc, count, st);
+        {
+          ProfScope ps(c, prof, MIPT_K_INTERSECT, n, st);
+          launch_intersect(c->dev, rc, q[cur], n, hit_t, hit_prim, dc, count, st);
+        }
+        {
+          ProfScope ps(c, prof, MIPT_K_SHADE, n, st);
+          launch_shade(c->dev, rc, q[cur], n, hit_t, hit_prim, q[cur ^ 1], sl, bc, accum, dc, count, st);
+        }
         BatchCounts h;
         HIP_TRY(c, hipMemcpyAsync(&h, bc, sizeof(h), hipMemcpyDeviceToHost, st));
         HIP_TRY(c, hipStreamSynchronize(st));
         if (h.overflow || h.next_rays > cap || h.shades > cap)
-          return set_err(c, MIPT_ERR_LIMIT,
-                         "path tree outgrew the ray queue at depth %d (%u rays, capacity %u): lower max_depth or batch_samples",
-                         depth, h.next_rays, cap);
+          return set_err(c, MIPT_ERR_DEVICE, "internal error: ray queue overflow (%u rays, capacity %u)", h.next_rays, cap);
         if (count) {
           tot.path_rays += n;
           tot.ray_stages += 2ull * n + h.shades;
           tot.shadow_rays += (uint64_t)h.shades * (uint64_t)c->dev.rays_per_hit;
         }
-        if (h.shades) launch_shadow(c->dev, rc, sl, h.shades, accum, dc, count, st);
-        n = h.next_rays;
+        if (h.shades) {
+          ProfScope ps(c, prof, MIPT_K_SHADOW, (uint64_t)h.shades * (uint64_t)c->dev.rays_per_hit, st);
+          launch_shadow(c->dev, rc, sl, h.shades, accum, dc, count, st);
+        }
+        uint32_t m = h.next_rays;
         cur ^= 1;
+        if (m > chunk) {
+          // the tree is growing: park the excess on the overflow stack
+          uint32_t excess = m - chunk;
+          if ((r = ensure_spill(c, spilled, excess, st)) != MIPT_OK) return r;
+          launch_copy_rays(q[cur], chunk, carve_queue(c->spill.p, (uint32_t)c->spill_cap), spilled, excess, st);
+          spilled += excess;
+          m = chunk;
+        } else if (m < chunk && spilled > 0) {
+          uint32_t take = (uint32_t)std::min<uint64_t>(chunk - m, spilled);
+          launch_copy_rays(carve_queue(c->spill.p, (uint32_t)c->spill_cap), spilled - take, q[cur], m, take, st);
+          spilled -= take;
+          m += take;
+        }
+        n = m;
       }
-      launch_resolve(rc, accum, d_rows, p0, npix, ns, d_sum, dc, st);
+      {
+        ProfScope ps(c, prof, MIPT_K_RESOLVE, (uint64_t)npix, st);
+        launch_resolve(rc, accum, d_rows, p0, npix, ns, d_sum, dc, st);
+      }
     }
   }
   HIP_TRY(c, hipStreamSynchronize(st));
+  if (prof) collect_spans(c);
   HIP_TRY(c, hipGetLastError());
   return MIPT_OK;
 }
@@ -524,8 +633,10 @@ int mipt_get_counters(mipt_ctx *c, mipt_counters *out) {
     HIP_TRY(c, hipSetDevice(c->device));
     DeviceCounters d;
     HIP_TRY(c, hipMemcpy(&d, c->dcount.p, sizeof(d), hipMemcpyDeviceToHost));
-    out->node_visits = d.node_visits;
-    out->prim_tests = d.prim_tests;
+    out->node_visits = d.closest_nodes + d.shadow_nodes;
+    out->prim_tests = d.closest_prims + d.shadow_prims;
+    out->shadow_node_visits = d.shadow_nodes;
+    out->shadow_prim_tests = d.shadow_prims;
     out->shaded_hits = d.shaded_hits;
     out->nan_samples = d.nan_samples;
   }
@@ -535,10 +646,17 @@ int mipt_get_counters(mipt_ctx *c, mipt_counters *out) {
 int mipt_reset_counters(mipt_ctx *c) {
   if (!c) return set_err(nullptr, MIPT_ERR_INVALID, "null context");
   c->totals = mipt_counters{};
+  c->ktimes = mipt_kernel_times{};
   if (c->dcount.p) {
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipMemset(c->dcount.p, 0, sizeof(DeviceCounters)));
   }
+  return MIPT_OK;
+}
+
+int mipt_get_kernel_times(mipt_ctx *c, mipt_kernel_times *out) {
+  if (!c || !out) return set_err(c, MIPT_ERR_INVALID, "null argument");
+  *out = c->ktimes;
   return MIPT_OK;
 }
 

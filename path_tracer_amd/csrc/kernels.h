@@ -16,7 +16,7 @@ struct RayQueue {
   double *dx, *dy, *dz;  // unit direction
   double *tx, *ty, *tz;  // throughput of the edge (what its radiance is multiplied by)
   uint64_t *key;         // random-stream key of the path node this ray arrives at
-  uint32_t *slot;        // sample accumulator the edge deposits into
+  uint32_t *slot;        // depth << 24 | sample accumulator the edge deposits into
 };
 constexpr size_t kRayBytes = 9 * sizeof(double) + sizeof(uint64_t) + sizeof(uint32_t);
 
@@ -30,7 +30,9 @@ struct ShadeList {
 };
 
 struct DeviceCounters {
-  unsigned long long path_rays, shadow_rays, shaded_hits, node_visits, prim_tests, ray_stages, nan_samples, samples;
+  unsigned long long shaded_hits, nan_samples;
+  unsigned long long closest_nodes, closest_prims;  // intersect kernel
+  unsigned long long shadow_nodes, shadow_prims;    // shadow kernel
 };
 
 struct BatchCounts {
@@ -56,8 +58,9 @@ void launch_generate(const SceneDev &S, const RenderConst &rc, const int *rows, 
 void launch_intersect(const SceneDev &S, const RenderConst &rc, RayQueue q, uint32_t n, double *hit_t, int *hit_prim,
                       DeviceCounters *dc, bool count, hipStream_t st);
 void launch_shade(const SceneDev &S, const RenderConst &rc, RayQueue q, uint32_t n, const double *hit_t,
-                  const int *hit_prim, int depth, RayQueue next, ShadeList sl, BatchCounts *bc, double *accum,
+                  const int *hit_prim, RayQueue next, ShadeList sl, BatchCounts *bc, double *accum,
                   DeviceCounters *dc, bool count, hipStream_t st);
+void launch_copy_rays(RayQueue src, uint64_t src_off, RayQueue dst, uint64_t dst_off, uint32_t n, hipStream_t st);
 void launch_shadow(const SceneDev &S, const RenderConst &rc, ShadeList sl, uint32_t n_shades, double *accum,
                    DeviceCounters *dc, bool count, hipStream_t st);
 void launch_resolve(const RenderConst &rc, const double *accum, const int *rows, int64_t first_pixel, int n_pixels,

@@ -136,7 +136,7 @@ __global__ void __launch_bounds__(kBlock) k_generate(SceneDev S, RenderConst rc,
   q.dx[idx] = dir.x; q.dy[idx] = dir.y; q.dz[idx] = dir.z;
   q.tx[idx] = 1.0; q.ty[idx] = 1.0; q.tz[idx] = 1.0;
   q.key[idx] = sample_key(rc.seed, (uint64_t)i + (uint64_t)j * (uint64_t)rc.width, (uint64_t)(sample0 + (int)k));
-  q.slot[idx] = idx;
+  q.slot[idx] = idx;  // depth 0 in the high byte
 }
 
 // --------------------------------------------------------------- intersect ----
@@ -154,15 +154,15 @@ __global__ void __launch_bounds__(kBlock) k_intersect(SceneDev S, RenderConst rc
     hit_prim[idx] = h.prim;
   }
   if (COUNT) {
-    wave_count(&dc->node_visits, tc.nodes);
-    wave_count(&dc->prim_tests, tc.prims);
+    wave_count(&dc->closest_nodes, tc.nodes);
+    wave_count(&dc->closest_prims, tc.prims);
   }
 }
 
 // ------------------------------------------------------------------- shade ----
 template <bool COUNT>
 __global__ void __launch_bounds__(kBlock) k_shade(SceneDev S, RenderConst rc, RayQueue q, uint32_t n, const double *__restrict__ hit_t,
-                                                   const int *__restrict__ hit_prim, int depth, RayQueue nq, ShadeList sl, BatchCounts *bc,
+                                                   const int *__restrict__ hit_prim, RayQueue nq, ShadeList sl, BatchCounts *bc,
                                                    double *accum, DeviceCounters *dc) {
   uint32_t idx = blockIdx.x * kBlock + threadIdx.x;
   bool live = idx < n;
@@ -170,6 +170,7 @@ __global__ void __launch_bounds__(kBlock) k_shade(SceneDev S, RenderConst rc, Ra
   d3 P{0, 0, 0}, N{0, 0, 0}, W{0, 0, 0}, wdir{0, 0, 0}, rdir{0, 0, 0}, Tb{0, 0, 0}, Tm{0, 0, 0};
   uint64_t key = 0;
   uint32_t slot = 0;
+  int depth = 0;
   bool shaded = false;
   if (live) {
     int prim = hit_prim[idx];
@@ -177,7 +178,9 @@ __global__ void __launch_bounds__(kBlock) k_shade(SceneDev S, RenderConst rc, Ra
     d3 d{q.dx[idx], q.dy[idx], q.dz[idx]};
     d3 T{q.tx[idx], q.ty[idx], q.tz[idx]};
     key = q.key[idx];
-    slot = q.slot[idx];
+    uint32_t sd = q.slot[idx];  // depth << 24 | sample slot
+    slot = sd & 0x00ffffffu;
+    depth = (int)(sd >> 24);
     if (prim < 0) {
       // miss branch, RayTracer.cpp:279-304
       if (S.has_cubemap) deposit(accum, slot, T * cube_color(S, d));
@@ -267,7 +270,7 @@ __global__ void __launch_bounds__(kBlock) k_shade(SceneDev S, RenderConst rc, Ra
       nq.dx[ib] = wdir.x; nq.dy[ib] = wdir.y; nq.dz[ib] = wdir.z;
       nq.tx[ib] = Tb.x; nq.ty[ib] = Tb.y; nq.tz[ib] = Tb.z;
       nq.key[ib] = mix64(key, SLOT_CHILD_BOUNCE);
-      nq.slot[ib] = slot;
+      nq.slot[ib] = slot | ((uint32_t)(depth + 1) << 24);
     } else {
       bc->overflow = 1;
     }
@@ -279,7 +282,7 @@ __global__ void __launch_bounds__(kBlock) k_shade(SceneDev S, RenderConst rc, Ra
       nq.dx[im] = rdir.x; nq.dy[im] = rdir.y; nq.dz[im] = rdir.z;
       nq.tx[im] = Tm.x; nq.ty[im] = Tm.y; nq.tz[im] = Tm.z;
       nq.key[im] = mix64(key, SLOT_CHILD_MIRROR);
-      nq.slot[im] = slot;
+      nq.slot[im] = slot | ((uint32_t)(depth + 1) << 24);
     } else {
       bc->overflow = 1;
     }
@@ -419,8 +422,8 @@ __global__ void __launch_bounds__(kBlock) k_shadow(SceneDev S, RenderConst rc, S
   bool head = (lane == 0) || (ph != h);
   if (head && h != 0xffffffffu) deposit(accum, slot, v);
   if (COUNT) {
-    wave_count(&dc->node_visits, tc.nodes);
-    wave_count(&dc->prim_tests, tc.prims);
+    wave_count(&dc->shadow_nodes, tc.nodes);
+    wave_count(&dc->shadow_prims, tc.prims);
   }
 }
 
@@ -518,13 +521,30 @@ void launch_intersect(const SceneDev &S, const RenderConst &rc, RayQueue q, uint
     hipLaunchKernelGGL(k_intersect<false>, dim3(grid_for(n)), dim3(kBlock), stack_bytes(S), st, S, rc, q, n, hit_t, hit_prim, dc);
 }
 
-void launch_shade(const SceneDev &S, const RenderConst &rc, RayQueue q, uint32_t n, const double *hit_t, const int *hit_prim, int depth,
+void launch_shade(const SceneDev &S, const RenderConst &rc, RayQueue q, uint32_t n, const double *hit_t, const int *hit_prim,
                   RayQueue next, ShadeList sl, BatchCounts *bc, double *accum, DeviceCounters *dc, bool count, hipStream_t st) {
   if (!n) return;
   if (count)
-    hipLaunchKernelGGL(k_shade<true>, dim3(grid_for(n)), dim3(kBlock), 0, st, S, rc, q, n, hit_t, hit_prim, depth, next, sl, bc, accum, dc);
+    hipLaunchKernelGGL(k_shade<true>, dim3(grid_for(n)), dim3(kBlock), 0, st, S, rc, q, n, hit_t, hit_prim, next, sl, bc, accum, dc);
   else
-    hipLaunchKernelGGL(k_shade<false>, dim3(grid_for(n)), dim3(kBlock), 0, st, S, rc, q, n, hit_t, hit_prim, depth, next, sl, bc, accum, dc);
+    hipLaunchKernelGGL(k_shade<false>, dim3(grid_for(n)), dim3(kBlock), 0, st, S, rc, q, n, hit_t, hit_prim, next, sl, bc, accum, dc);
+}
+
+// Moves `n` ray records between queues (spill to / refill from the overflow stack).
+__global__ void __launch_bounds__(kBlock) k_copy_rays(RayQueue src, uint64_t src_off, RayQueue dst, uint64_t dst_off, uint32_t n) {
+  uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  uint64_t a = src_off + i, b = dst_off + i;
+  dst.ox[b] = src.ox[a]; dst.oy[b] = src.oy[a]; dst.oz[b] = src.oz[a];
+  dst.dx[b] = src.dx[a]; dst.dy[b] = src.dy[a]; dst.dz[b] = src.dz[a];
+  dst.tx[b] = src.tx[a]; dst.ty[b] = src.ty[a]; dst.tz[b] = src.tz[a];
+  dst.key[b] = src.key[a];
+  dst.slot[b] = src.slot[a];
+}
+
+void launch_copy_rays(RayQueue src, uint64_t src_off, RayQueue dst, uint64_t dst_off, uint32_t n, hipStream_t st) {
+  if (!n) return;
+  hipLaunchKernelGGL(k_copy_rays, dim3(grid_for(n)), dim3(kBlock), 0, st, src, src_off, dst, dst_off, n);
 }
 
 void launch_shadow(const SceneDev &S, const RenderConst &rc, ShadeList sl, uint32_t n_shades, double *accum, DeviceCounters *dc, bool count,

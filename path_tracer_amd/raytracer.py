@@ -99,6 +99,11 @@ class Context:
         self._check(self.lib.mipt_get_counters(self._h, C.byref(c)))
         return c.as_dict()
 
+    def kernel_times(self) -> dict:
+        t = abi.KernelTimes()
+        self._check(self.lib.mipt_get_kernel_times(self._h, C.byref(t)))
+        return t.as_dict()
+
     def reset_counters(self):
         self._check(self.lib.mipt_reset_counters(self._h))
 

@@ -58,8 +58,10 @@ def make_scene(n_triangles: int = 1_000_000, seed: int = 0xC4, n_area_lights: in
     rng = np.random.RandomState(seed)
     sc = Scene()
     cam = Camera()
-    cam.set_eye([0.0, 6.0, 6.0])
-    cam.set_look([0.0, -0.28, -1.0], [0.0, 1.0, 0.0])
+    # off-axis on purpose: a camera in the plane x = 0 looking down -z would send a whole
+    # pixel column exactly along the terrain grid's edges
+    cam.set_eye([0.37, 6.0, 6.0])
+    cam.set_look([0.03, -0.28, -1.0], [0.0, 1.0, 0.0])
     cam.set_fov(45.0)
     cam.set_aspect(16.0 / 9.0)
     sc.camera = cam
@@ -104,21 +106,36 @@ def make_scene(n_triangles: int = 1_000_000, seed: int = 0xC4, n_area_lights: in
 
     # ---- blobs: displaced icospheres in 12 meshes ---------------------------------------
     remaining = max(0, n_triangles - terrain_tris)
-    level = 4 if remaining >= 12 * 5120 else (3 if remaining >= 12 * 1280 else (2 if remaining >= 12 * 320 else 1))
+    # Subdivision level: as coarse as keeps the blob count at or below ~150, so that the
+    # blobs can sit on a jittered grid without touching each other or the ground.  (The
+    # reference's estimator multiplies rays in narrow gaps between glossy surfaces — each
+    # hit spawns up to two children — so near-contact geometry makes path trees explode.)
+    level = 1
+    while level < 8 and remaining / (20 * 4 ** level) > 150:
+        level += 1
     bv, bf = _icosphere(level)
     per_blob = len(bf)
     n_blobs = max(12, int(round(remaining / per_blob)))
+    cols = int(math.ceil(math.sqrt(n_blobs * 36.0 / 46.0)))
+    rows_ = int(math.ceil(n_blobs / cols))
+    cell = min(36.0 / cols, 46.0 / rows_)
+    rmax = min(1.5, 0.36 * cell)
+    order = rng.permutation(cols * rows_)[:n_blobs]
     blobs = [[] for _ in range(12)]
     for b in range(n_blobs):
-        blobs[b % 12].append(b)
+        blobs[b % 12].append(int(order[b]))
     for mi in range(12):
         vs, fs, ns = [], [], []
         off = 0
         smooth = mi % 2 == 0
-        for _ in blobs[mi]:
-            radius = rng.uniform(0.5, 1.6)
-            cx, cz = rng.uniform(-18.0, 18.0), rng.uniform(-58.0, -12.0)
-            cy = float(_terrain_height(np.array(cx), np.array(cz))) + radius * rng.uniform(0.6, 2.5)
+        for cell_id in blobs[mi]:
+            gx, gz = cell_id % cols, cell_id // cols
+            radius = rng.uniform(0.55, 1.0) * rmax
+            jitter = 0.5 * cell - 1.15 * radius
+            cx = -18.0 + (gx + 0.5) * (36.0 / cols) + rng.uniform(-1.0, 1.0) * max(0.0, min(jitter, 0.5 * 36.0 / cols - 1.15 * radius))
+            cz = -58.0 + (gz + 0.5) * (46.0 / rows_) + rng.uniform(-1.0, 1.0) * max(0.0, min(jitter, 0.5 * 46.0 / rows_ - 1.15 * radius))
+            # float well clear of the terrain (whose height varies by < 1.5 over a blob's footprint)
+            cy = float(_terrain_height(np.array(cx), np.array(cz))) + 1.5 + radius * rng.uniform(2.0, 3.5)
             cy = min(cy, 8.0 - radius * 1.2)
             freq = rng.uniform(2.0, 5.0)
             disp = 1.0 + 0.12 * np.sin(freq * bv[:, 0] + 1.7) * np.cos(freq * bv[:, 1]) * np.sin(freq * bv[:, 2] + 0.3)
@@ -140,7 +157,7 @@ def make_scene(n_triangles: int = 1_000_000, seed: int = 0xC4, n_area_lights: in
     floor.ka = np.array([0.1, 0.1, 0.1])
     sc.materials.append(floor)
     T = np.eye(4)
-    T[:3, 3] = [0.0, -3.4, -35.0]
+    T[:3, 3] = [0.0, -4.2, -35.0]
     Sc = np.diag([220.0, 220.0, 220.0, 1.0])
     a = -math.pi / 2.0
     Rx = np.array([[1, 0, 0, 0], [0, math.cos(a), -math.sin(a), 0], [0, math.sin(a), math.cos(a), 0], [0, 0, 0, 1.0]])
@@ -149,17 +166,17 @@ def make_scene(n_triangles: int = 1_000_000, seed: int = 0xC4, n_area_lights: in
     # ---- lights -------------------------------------------------------------------------
     att = np.array([1.0, 0.0, 0.0], dtype=np.float32)
     if n_area_lights <= 1:
-        sc.lights.append(LightRec(abi.LIGHT_RECT_AREA, np.array([1.0, 0.97, 0.9]), position=np.array([-6.0, 16.0, -40.0]),
+        sc.lights.append(LightRec(abi.LIGHT_RECT_AREA, np.array([2.4, 2.3, 2.1]), position=np.array([-6.0, 16.0, -40.0]),
                                   u=np.array([1.0, 0.0, 0.0]), v=np.array([0.0, 0.0, 1.0]), uL=10.0, vL=10.0, atten=att))
     else:
         side = int(round(math.sqrt(n_area_lights)))
-        inten = 3.0 / n_area_lights
+        inten = 6.0 / n_area_lights
         for a_ in range(side):
             for b_ in range(side):
                 pos = np.array([-18.0 + 36.0 * a_ / max(1, side - 1), 16.0, -58.0 + 46.0 * b_ / max(1, side - 1)])
                 sc.lights.append(LightRec(abi.LIGHT_RECT_AREA, np.array([inten, inten, inten]), position=pos, u=np.array([1.0, 0.0, 0.0]),
                                           v=np.array([0.0, 0.0, 1.0]), uL=1.0, vL=1.0, atten=att))
-    sc.lights.append(LightRec(abi.LIGHT_DIRECTIONAL, np.array([0.55, 0.55, 0.6]), direction=np.array([-0.4, -1.0, -0.3])))
+    sc.lights.append(LightRec(abi.LIGHT_DIRECTIONAL, np.array([1.3, 1.3, 1.4]), direction=np.array([-0.4, -1.0, -0.3])))
 
     if cubemap:
         sc.cubemap = make_sky_cubemap(64)
