@@ -197,5 +197,5 @@ def make_sky_cubemap(size: int = 64):
 
 
 def small_mesh_scene(seed: int = 7, n_triangles: int = 20000, smooth: bool = True) -> Scene:
-    """A small version of the same layout for parity tests (oracle finishes in seconds)."""
+    """A small version of the same layout for parity tests (a CPU render finishes in seconds)."""
     return make_scene(n_triangles=n_triangles, seed=seed)

@@ -1,0 +1,72 @@
+"""Multi-rank path on the CPU: two gloo ranks shard one frame (by sample range and by row
+bands), fill their radiance sums, and the single collective of the render brings them
+together on rank 0.  The per-rank sums come from the CPU oracle here (no GPU in this
+test); the sharding plan and the collective are the product code under test."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, mode, out_path):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+
+    from oracle.binding import Oracle
+    from path_tracer_amd import abi
+    from path_tracer_amd.dist import combine, shard_params
+    from tests.conftest import load_scene
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sc = load_scene("areaLight")
+        base = abi.default_params(20, 14, spp=6, band_rows=3)
+        p = shard_params(base, rank, world, mode)
+        mean = Oracle(sc).render(p)                       # zero outside the shard; mean = sum / spp
+        d_sum = torch.from_numpy((mean * base.spp).reshape(-1).copy())
+        full = combine(d_sum, base, mode, dst=0)
+        if rank == 0:
+            np.save(out_path, full.numpy().reshape(14, 20, 3) / base.spp)
+        else:
+            assert full is None
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["samples", "tiles"])
+def test_two_ranks_reproduce_the_single_rank_frame(mode, tmp_path):
+    import torch.multiprocessing as mp
+
+    from oracle.binding import Oracle
+    from path_tracer_amd import abi
+    from tests.conftest import load_scene
+
+    out = str(tmp_path / "frame.npy")
+    port = 29500 + (os.getpid() % 2000) + (0 if mode == "samples" else 1)
+    mp.spawn(_worker, args=(2, port, mode, out), nprocs=2, join=True)
+    got = np.load(out)
+    want = Oracle(load_scene("areaLight")).render(abi.default_params(20, 14, spp=6, band_rows=3))
+    if mode == "tiles":
+        assert np.array_equal(got, want)                  # disjoint rows: bit for bit
+    else:
+        assert np.allclose(got, want, rtol=0, atol=1e-15)  # fp64 summation order only
+
+
+def test_shard_plans_partition_the_work():
+    from path_tracer_amd import abi
+    from path_tracer_amd.dist import owned_rows, shard_params
+
+    base = abi.default_params(64, 37, spp=10, band_rows=4)
+    for world in (1, 2, 3, 8):
+        rows = np.concatenate([owned_rows(shard_params(base, r, world, "tiles")) for r in range(world)])
+        assert sorted(rows.tolist()) == list(range(37))
+        spans = [(p.sample_begin, p.sample_end) for p in (shard_params(base, r, world, "samples") for r in range(world))]
+        assert spans[0][0] == 0 and spans[-1][1] == 10 and all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+    with pytest.raises(ValueError):
+        shard_params(base, 2, 2, "tiles")

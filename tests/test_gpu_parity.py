@@ -1,0 +1,390 @@
+"""GPU parity: the HIP path through the C ABI (libmipt.so) against the CPU oracle on the
+same seeded inputs, plus size-independent properties at the benchmark's full frame size.
+
+Stated tolerances.  Everything on the GPU path that decides a hit is fp64, so per-ray
+results agree to rounding: |dt| <= 1e-9 * max(1, t), normals to 1e-9, the same primitive
+on every ray.  Images (mean of per-sample-clamped radiance, float32): |d| <= 1e-5 per
+channel on >= 99.8 % of the pixels (a ray that grazes an edge may fall either way after a
+different rounding, which changes that pixel), RGB8 within 1 LSB on those pixels.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+
+from path_tracer_amd import abi
+from tests import util as U
+from tests.conftest import SCENE_NAMES
+
+pytestmark = pytest.mark.gpu
+
+PIX_TOL = 1e-5
+PIX_FRAC = 0.998
+
+
+def upload(gpu, sc):
+    gpu.upload_scene(sc)
+    return gpu
+
+
+def assert_images_match(f32, ref, rgb8=None, ref8=None, frac=PIX_FRAC):
+    diff = np.abs(f32.astype(np.float64) - ref).max(axis=2)
+    ok = diff <= PIX_TOL
+    assert ok.mean() >= frac, f"only {ok.mean():.5f} of the pixels within {PIX_TOL} (max {diff.max():.3e})"
+    if rgb8 is not None:
+        d8 = np.abs(rgb8.astype(np.int32) - ref8.astype(np.int32)).max(axis=2)
+        assert (d8[ok] <= 1).all()
+
+
+def assert_rays_match(gpu_res, orc_res, min_same=1.0):
+    tg, pg, ng = gpu_res
+    to, po, no = orc_res
+    same = pg == po
+    assert same.mean() >= min_same, f"{(~same).sum()} of {len(same)} rays found a different primitive"
+    hit = same & (po >= 0)
+    assert np.all(np.abs(tg[hit] - to[hit]) <= 1e-9 * np.maximum(1.0, to[hit]))
+    assert np.all(np.abs(ng[hit] - no[hit]) <= 1e-9)
+    assert np.all(tg[same & (po < 0)] == to[same & (po < 0)])
+
+
+# -------------------------------------------------------------------- per ray
+@pytest.mark.parametrize("name", SCENE_NAMES)
+def test_closest_hit_matches_the_oracle_per_ray(name, gpu, scenes, oracles):
+    sc, orc = scenes(name), oracles(name)
+    upload(gpu, sc)
+    org, d = U.camera_rays(sc, 20000, seed=1)
+    res = orc.intersect(org, d)
+    assert_rays_match(gpu.intersect(org, d), res)
+    t, prim, n = res
+    hit = prim >= 0
+    P = org[hit] + t[hit, None] * d[hit]
+    # bounce-style rays: origin eps along the direction (RayTracer.cpp:259)
+    d2 = U.random_dirs(len(P), seed=2)
+    assert_rays_match(gpu.intersect(P + d2 * 1e-8, d2), orc.intersect(P + d2 * 1e-8, d2))
+    # mirror-style rays: origin eps along the normal (RayTracer.cpp:270-271)
+    r = d[hit] - n[hit] * (2.0 * np.sum(n[hit] * d[hit], axis=1))[:, None]
+    assert_rays_match(gpu.intersect(P + n[hit] * 1e-8, r), orc.intersect(P + n[hit] * 1e-8, r))
+
+
+def test_closest_hit_on_a_triangle_mesh_scene(gpu, oracle_lib):
+    from path_tracer_amd import synth
+
+    sc = synth.make_scene(20000, seed=7)
+    orc = oracle_lib.Oracle(sc)
+    upload(gpu, sc)
+    org, d = U.camera_rays(sc, 20000, seed=3)
+    res = orc.intersect(org, d)
+    assert_rays_match(gpu.intersect(org, d), res, min_same=0.9999)
+    t, prim, n = res
+    hit = prim >= 0
+    assert hit.mean() > 0.5
+    P = org[hit] + t[hit, None] * d[hit]
+    d2 = U.random_dirs(len(P), seed=4)
+    assert_rays_match(gpu.intersect(P + d2 * 1e-8, d2), orc.intersect(P + d2 * 1e-8, d2), min_same=0.9999)
+    r = d[hit] - n[hit] * (2.0 * np.sum(n[hit] * d[hit], axis=1))[:, None]
+    assert_rays_match(gpu.intersect(P + n[hit] * 1e-8, r), orc.intersect(P + n[hit] * 1e-8, r), min_same=0.9999)
+
+
+def test_transformed_mesh_matches_local_space_reference(gpu, oracle_lib):
+    # the library pre-transforms triangles to world space; the reference intersects in the
+    # mesh's local space (scene.cpp:13-40).  Non-uniform scale + rotation + mirroring.
+    nrm = np.array([[1, 0, 1], [0, 0, 1], [0, 0, 1], [0, 1, 1]], float)
+    xf = U.translate(0.3, -0.2, -4) @ U.rot_y(0.7) @ U.rot_x(-0.4) @ U.scale(2.0, -0.7, 1.3)
+    sc = U.scene([(abi.OBJ_TRIMESH, xf, U.material(), 0), (abi.OBJ_TRIMESH, U.translate(0, 0, -6) @ U.scale(3), U.material(), 1)],
+                 meshes=[U.quad_mesh(nrm), U.quad_mesh()], cam=U.camera(eye=(0, 0, 3)))
+    orc = oracle_lib.Oracle(sc)
+    upload(gpu, sc)
+    org, d = U.camera_rays(sc, 20000, seed=8)
+    res = orc.intersect(org, d)
+    assert (res[1] >= 0).mean() > 0.3
+    assert_rays_match(gpu.intersect(org, d), res, min_same=0.9999)
+
+
+def test_coincident_spheres_resolve_like_the_reference(gpu, scenes, oracles):
+    # the six coincident pairs of spheres.json differ in roughness: picking the other one changes the image
+    sc, orc = scenes("spheres"), oracles("spheres")
+    upload(gpu, sc)
+    centres = np.array([o.xform[:3, 3] for o in sc.objects if o.type == abi.OBJ_SPHERE])
+    uniq, counts = np.unique(np.round(centres, 9), axis=0, return_counts=True)
+    pairs = uniq[counts == 2]
+    assert len(pairs) == 6
+    eye = np.asarray(sc.camera.eye)
+    d = pairs - eye
+    d /= np.linalg.norm(d, axis=1)[:, None]
+    tg, pg, _ = gpu.intersect(np.repeat(eye[None], 6, 0), d)
+    to, po, _ = orc.intersect(np.repeat(eye[None], 6, 0), d)
+    assert np.array_equal(pg, po) and np.array_equal(tg, to)
+
+
+@pytest.mark.parametrize("name", ["spheres", "cornellBoxes", "hitchcockBRDF", "singleSphere", "spheresDirectional"])
+def test_shadow_attenuation_matches_per_light(name, gpu, scenes, oracles):
+    sc, orc = scenes(name), oracles(name)
+    upload(gpu, sc)
+    org, d = U.camera_rays(sc, 4000, seed=5)
+    t, prim, n = orc.intersect(org, d)
+    hit = prim >= 0
+    fire = org[hit] + t[hit, None] * d[hit] + n[hit] * 1e-8 * 3.0      # material.cpp:117
+    keys = np.arange(len(fire), dtype=np.uint64) * np.uint64(7919) + np.uint64(13)
+    for flags in (0, abi.FLAG_FIXED_AREA_PATTERN):
+        p = abi.default_params(8, 8, flags=flags)
+        for li in range(len(sc.lights)):
+            a = gpu.shadow_attenuation(p, li, fire, keys)
+            b = orc.shadow_attenuation(p, li, fire, keys)
+            bad = np.abs(a - b).max(axis=1) > 1e-9
+            assert bad.mean() <= 2e-3, f"light {li}: {bad.sum()} of {len(fire)} shading points differ"
+
+
+def test_translucent_shadow_walk(gpu, oracle_lib):
+    glass = U.material(kd=(0.2, 0.2, 0.2), kt=(0.5, 0.25, 0.9))
+    floor = U.material(kd=(0.8, 0.8, 0.8))
+    sc = U.scene([(abi.OBJ_BOX, U.translate(0, 2, 0) @ U.scale(3, 1, 3), glass), (abi.OBJ_SPHERE, U.translate(2.5, 2, 0.5), glass),
+                  (abi.OBJ_SQUARE, U.rot_x(-math.pi / 2) @ U.scale(30), floor)],
+                 lights=[U.point_light((0.5, 9, 0.5), atten=(1, 0, 0)), U.dir_light((0.1, -1, 0.2)), U.area_light((-1, 8, -1), (1, 0, 0), (0, 0, 1), 2, 2)],
+                 cam=U.camera(eye=(0, 6, 12), viewdir=(0, -0.4, -1)))
+    orc = oracle_lib.Oracle(sc)
+    upload(gpu, sc)
+    xs, zs = np.meshgrid(np.linspace(-5, 5, 40), np.linspace(-5, 5, 40))
+    fire = np.stack([xs.ravel(), np.full(xs.size, 3e-8), zs.ravel()], 1)
+    keys = np.arange(len(fire), dtype=np.uint64)
+    p = abi.default_params(8, 8)
+    for li in range(3):
+        a, b = gpu.shadow_attenuation(p, li, fire, keys), orc.shadow_attenuation(p, li, fire, keys)
+        assert ((b > 0) & (b < 0.99)).any()                       # some rays really pass through glass
+        bad = np.abs(a - b).max(axis=1) > 1e-9
+        assert bad.mean() <= 5e-3
+    pr = abi.default_params(48, 48, spp=2)
+    f32, rgb8 = gpu.render(pr)
+    ref, ref8 = orc.render(pr, threads=4, want_rgb8=True)
+    assert_images_match(f32, ref, rgb8, ref8, frac=0.995)
+
+
+# ---------------------------------------------------------------------- images
+@pytest.mark.parametrize("name", SCENE_NAMES)
+def test_deterministic_one_spp_image(name, gpu, scenes, oracles):
+    """Fixed seeds, Russian roulette off, depth cap 4, fixed area-light pattern."""
+    sc, orc = scenes(name), oracles(name)
+    upload(gpu, sc)
+    w, h = (256, 144) if name == "hitchcockBRDF" else (160, 160)
+    p = abi.default_params(w, h, spp=1, rr_q=0.0, max_depth=4, flags=abi.FLAG_FIXED_AREA_PATTERN)
+    f32, rgb8 = gpu.render(p)
+    ref, ref8 = orc.render(p, threads=8, want_rgb8=True)
+    assert_images_match(f32, ref, rgb8, ref8)
+
+
+@pytest.mark.parametrize("name", ["spheres", "cornellBoxes", "hitchcockBRDF", "areaLight"])
+def test_stochastic_image_same_random_streams(name, gpu, scenes, oracles):
+    """Reference settings (q = 0.1, random area samples): both sides draw the same counter-based
+    numbers, so the images agree pixel by pixel, not just statistically."""
+    sc, orc = scenes(name), oracles(name)
+    upload(gpu, sc)
+    p = abi.default_params(96, 96, spp=8)
+    f32, rgb8 = gpu.render(p)
+    ref, ref8, cnt = orc.render(p, threads=8, want_rgb8=True, want_counters=True)
+    assert_images_match(f32, ref, rgb8, ref8)
+    # the same path trees: identical ray and hit counts
+    gpu.reset_counters()
+    pc = abi.default_params(96, 96, spp=8, flags=abi.FLAG_COUNTERS)
+    gpu.render(pc, want_f32=False, want_rgb8=False)
+    c = gpu.counters()
+    assert c["samples"] == cnt["samples"] == 96 * 96 * 8
+    for k in ("path_rays", "shaded_hits"):
+        assert abs(c[k] - cnt[k]) <= 2e-4 * cnt[k] + 2, (k, c[k], cnt[k])
+
+
+def test_mesh_scene_images(gpu, oracle_lib):
+    from path_tracer_amd import synth
+
+    sc = synth.make_scene(20000, seed=7)
+    orc = oracle_lib.Oracle(sc)
+    upload(gpu, sc)
+    p = abi.default_params(128, 72, spp=1, rr_q=0.0, max_depth=4, flags=abi.FLAG_FIXED_AREA_PATTERN)
+    f32, rgb8 = gpu.render(p)
+    ref, ref8 = orc.render(p, threads=8, want_rgb8=True)
+    assert ref.mean() > 0.02
+    assert_images_match(f32, ref, rgb8, ref8, frac=0.995)
+    p = abi.default_params(96, 54, spp=2)
+    f32, rgb8 = gpu.render(p)
+    ref, ref8 = orc.render(p, threads=8, want_rgb8=True)
+    assert_images_match(f32, ref, rgb8, ref8, frac=0.995)
+
+
+def test_cubemap_environment(gpu, oracle_lib, scenes):
+    from path_tracer_amd import synth
+    import copy
+
+    sc = copy.copy(scenes("singleSphere"))
+    sc.cubemap = synth.make_sky_cubemap(32)
+    orc = oracle_lib.Oracle(sc)
+    upload(gpu, sc)
+    p = abi.default_params(96, 96, spp=4)
+    f32, rgb8 = gpu.render(p)
+    ref, ref8 = orc.render(p, threads=8, want_rgb8=True)
+    assert ref.mean() > 0.2                                           # the sky is visible
+    assert_images_match(f32, ref, rgb8, ref8)
+
+
+def test_converged_render_is_within_the_noise_floor(gpu, scenes, oracles):
+    """Different seeds on the two sides: agreement must be statistical.  RMSD is raycheck.py's
+    (||a-b||_2 / sqrt(size) on float [0,1] RGB); the bound is 1.5x the RMSD between two oracle
+    renders with different seeds, and 0.02 absolute at 256 spp."""
+    sc, orc = scenes("areaLight"), oracles("areaLight")
+    upload(gpu, sc)
+    spp = 256
+    f32, _ = gpu.render(abi.default_params(48, 48, spp=spp, seed=5))
+    a = orc.render(abi.default_params(48, 48, spp=spp, seed=6), threads=8)
+    b = orc.render(abi.default_params(48, 48, spp=spp, seed=7), threads=8)
+    floor = U.rmsd(a, b)
+    got = U.rmsd(f32, a)
+    assert got <= 1.5 * floor + 1e-4 and got <= 0.02, (got, floor)
+
+
+# ------------------------------------------------------------- host interface
+def test_trace_pixel_is_the_rendered_pixel(gpu, scenes):
+    upload(gpu, scenes("cornellBoxes"))
+    p = abi.default_params(40, 40, spp=6)
+    f32, _ = gpu.render(p)
+    for (i, j) in ((0, 0), (13, 27), (39, 39)):
+        px = gpu.trace_pixel(p, i, j)
+        assert np.allclose(px, f32[j, i], rtol=0, atol=2e-7)
+
+
+def test_raytracer_shim_follows_the_reference_call_order(scenes):
+    from path_tracer_amd.raytracer import RayTracer
+
+    rt = RayTracer(0)
+    assert not rt.sceneLoaded() and np.array_equal(rt.tracePixel(0, 0), np.zeros(3))     # RayTracer.cpp:63-64
+    assert not rt.loadScene("/nonexistent/scene.json") and rt.last_alert
+    assert rt.loadScene(scenes("spheres"))
+    rt.overrides = {"spp": 4}
+    rt.traceSetup(32, 32)
+    assert rt.getBuffer()[0].sum() == 0                                                   # zero-filled (:427)
+    rt.traceImage(32, 32)
+    rt.waitRender()
+    buf, w, h = rt.getBuffer()
+    assert rt.checkRender() and (w, h) == (32, 32) and buf.shape == (32, 32, 3) and buf.dtype == np.uint8
+    assert buf[-4:].sum() == 0 and buf[:16].sum() > 0                                     # row 0 = bottom; sky on top
+    c = rt.tracePixel(10, 5)
+    assert np.array_equal(buf[5, 10], (255.0 * c).astype(np.int64).astype(np.uint8))      # truncation (:97-99)
+
+
+def test_sharding_is_exact_on_the_gpu(gpu, scenes):
+    import torch
+
+    upload(gpu, scenes("spheres"))
+    w, h = 64, 48
+    full = torch.zeros(3 * w * h, dtype=torch.float64, device="cuda")
+    gpu.render_accumulate(abi.default_params(w, h, spp=4, band_rows=4), full.data_ptr())
+    tiles = torch.zeros_like(full)
+    for r in range(3):
+        gpu.render_accumulate(abi.default_params(w, h, spp=4, band_rows=4, shard_index=r, shard_count=3), tiles.data_ptr())
+    samples = torch.zeros_like(full)
+    for (a, b) in ((0, 1), (1, 4)):
+        gpu.render_accumulate(abi.default_params(w, h, spp=4, band_rows=4, sample_begin=a, sample_end=b), samples.data_ptr())
+    batched = torch.zeros_like(full)
+    gpu.render_accumulate(abi.default_params(w, h, spp=4, band_rows=4, batch_samples=1000), batched.data_ptr())
+    torch.cuda.synchronize()
+    for other in (tiles, samples, batched):
+        assert float((other - full).abs().max()) <= 1e-12   # same samples, same streams; only fp64 add order differs
+    f = torch.zeros(3 * w * h, dtype=torch.float32, device="cuda")
+    b8 = torch.zeros(3 * w * h, dtype=torch.uint8, device="cuda")
+    gpu.resolve(full.data_ptr(), w, h, 4, f.data_ptr(), b8.data_ptr())
+    torch.cuda.synchronize()
+    mean = (full / 4).cpu().numpy()
+    assert np.array_equal(f.cpu().numpy(), mean.astype(np.float32))
+    assert np.array_equal(b8.cpu().numpy(), (255.0 * mean).astype(np.int64).astype(np.uint8))
+
+
+def test_growing_path_trees_spill_to_the_overflow_stack(gpu, oracle_lib):
+    # two facing mirrors: every hit spawns a bounce and a mirror ray (RayTracer.cpp:262,273),
+    # the tree doubles per level until the depth cap
+    mirror = U.material(kd=(0.3, 0.3, 0.3), ka=(0.1, 0.1, 0.1), roughness=0.0)
+    sc = U.scene([(abi.OBJ_SQUARE, U.translate(0, 0, -2) @ U.scale(400), mirror), (abi.OBJ_SQUARE, U.translate(0, 0, 2) @ U.scale(400), mirror)],
+                 lights=[U.point_light((0, 0.5, 0), atten=(1, 0, 0))], cam=U.camera(eye=(0, 0, 0)), ambient=(1, 1, 1))
+    orc = oracle_lib.Oracle(sc)
+    upload(gpu, sc)
+    p = abi.default_params(16, 16, spp=2, max_depth=12, batch_samples=128)
+    f32, _ = gpu.render(p, want_rgb8=False)
+    ref, cnt = orc.render(p, threads=8, want_counters=True)
+    assert cnt["path_rays"] > 40 * 16 * 16 * 2                        # the tree really grew
+    assert_images_match(f32, ref)
+
+
+# ------------------------------------------------------------------ edge cases
+def test_edge_cases(gpu, oracle_lib):
+    empty = U.scene([], lights=[U.dir_light((0, -1, 0))])
+    upload(gpu, empty)
+    f32, rgb8 = gpu.render(abi.default_params(5, 3, spp=2))
+    assert f32.shape == (3, 5, 3) and f32.sum() == 0 and rgb8.sum() == 0
+    t, prim, _ = gpu.intersect([[0, 0, 0]], [[0, 0, 1]])
+    assert prim[0] == -1 and t[0] == 1000.0
+    nolight = U.scene([(abi.OBJ_SPHERE, np.eye(4), U.material(ka=(0.2, 0.4, 0.6)))], ambient=(1, 1, 1), cam=U.camera(eye=(0, 0, 4)))
+    upload(gpu, nolight)
+    p = abi.default_params(1, 1, spp=3, rr_q=0.0, max_depth=1)
+    f32, _ = gpu.render(p)
+    ref = oracle_lib.Oracle(nolight).render(p)
+    assert np.allclose(f32, ref, atol=1e-7)
+    onetri = U.scene([(abi.OBJ_TRIMESH, np.eye(4), U.material(), 0)],
+                     meshes=[type(U.quad_mesh())(np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [0, 0, 0.0]]), np.array([[0, 1, 2], [0, 0, 3]], np.int32))],
+                     cam=U.camera(eye=(0.2, 0.2, 3)))
+    upload(gpu, onetri)                                              # the second face is degenerate and dropped (trimesh.h:139-141)
+    assert gpu.scene_stats()["prims"] == 1
+    t, prim, n = gpu.intersect([[0.2, 0.2, 3]], [[0, 0, -1]])
+    assert prim[0] == 0 and t[0] == pytest.approx(3.0) and np.allclose(n[0], [0, 0, 1])
+
+
+def test_errors_are_reported_not_swallowed(scenes):
+    from path_tracer_amd.raytracer import Context, MiptError
+
+    ctx = Context(0)
+    with pytest.raises(MiptError) as e:
+        ctx.render(abi.default_params(8, 8))
+    assert e.value.code == abi.ERR_NOSCENE
+    ctx.upload_scene(scenes("room"))
+    for bad in (dict(spp=0), dict(rr_q=1.0), dict(max_depth=0), dict(max_depth=300), dict(shard_index=2, shard_count=2), dict(area_samples=0)):
+        with pytest.raises(MiptError) as e:
+            ctx.render(abi.default_params(8, 8, **bad))
+        assert e.value.code == abi.ERR_INVALID
+    sc = scenes("room")
+    import copy
+    broken = copy.deepcopy(sc)
+    broken.objects[0].material = 99
+    with pytest.raises(MiptError):
+        ctx.upload_scene(broken)
+    with pytest.raises(MiptError):
+        Context(4096)
+    ctx.close()
+
+
+# --------------------------------------- properties at the benchmark's full size
+def test_full_size_frame_properties(gpu):
+    """1920x1080 on a 200k-triangle version of the benchmark scene: tile shards are disjoint and
+    add up to the unsharded frame, sample ranges add up, every mean lies in [0, 1], and the two
+    independent sums agree to fp64 rounding."""
+    import torch
+    from path_tracer_amd import synth
+
+    sc = synth.make_scene(200_000)
+    upload(gpu, sc)
+    w, h = 1920, 1080
+    full = torch.zeros(3 * w * h, dtype=torch.float64, device="cuda")
+    gpu.render_accumulate(abi.default_params(w, h, spp=2), full.data_ptr())
+    parts = []
+    for r in range(2):
+        t = torch.zeros_like(full)
+        gpu.render_accumulate(abi.default_params(w, h, spp=2, shard_index=r, shard_count=2, band_rows=8), t.data_ptr())
+        parts.append(t)
+    torch.cuda.synchronize()
+    rows = torch.arange(h, device="cuda")
+    own0 = ((rows // 8) % 2 == 0)
+    p0 = parts[0].view(h, -1)
+    p1 = parts[1].view(h, -1)
+    assert float(p0[~own0].abs().sum()) == 0 and float(p1[own0].abs().sum()) == 0
+    assert float((parts[0] + parts[1] - full).abs().max()) <= 1e-12
+    s = torch.zeros_like(full)
+    gpu.render_accumulate(abi.default_params(w, h, spp=2, sample_begin=0, sample_end=1), s.data_ptr())
+    gpu.render_accumulate(abi.default_params(w, h, spp=2, sample_begin=1, sample_end=2), s.data_ptr())
+    torch.cuda.synchronize()
+    assert float((s - full).abs().max()) <= 1e-12
+    assert float(full.min()) >= 0 and float(full.max()) <= 2.0 + 1e-12
+    assert float(full.mean()) > 0.05

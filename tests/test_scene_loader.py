@@ -1,0 +1,108 @@
+"""The host's JSON scene loader builds what JsonParser::parseScene builds
+(parser/JsonParser.cpp:447-515)."""
+import json
+import math
+
+import numpy as np
+import pytest
+
+from path_tracer_amd import abi
+from path_tracer_amd.scene import Scene, parse_json_scene
+
+
+def J(*items):
+    return json.dumps(list(items))
+
+
+def test_transform_stack_multiplies_outer_to_inner():
+    sc = parse_json_scene(J({"translate": [[1, 2, 3], [{"scale": [[2, 2, 2], [{"sphere": {}}]]}]]}))
+    m = sc.objects[0].xform                      # JsonParser.cpp:59-67: T * S
+    assert np.allclose(m @ [1, 0, 0, 1], [3, 2, 3, 1])
+    sc = parse_json_scene(J({"scale": [[2, 2, 2], [{"translate": [[1, 2, 3], [{"box": {}}]]}]]}))
+    assert np.allclose(sc.objects[0].xform @ [0, 0, 0, 1], [2, 4, 6, 1])
+
+
+def test_rotate_is_glm_rotate_in_radians_and_transform_is_column_major():
+    sc = parse_json_scene(J({"rotate": [[0, 0, 2], math.pi / 2, [{"square": {}}]]}))
+    assert np.allclose(sc.objects[0].xform @ [1, 0, 0, 1], [0, 1, 0, 1], atol=1e-15)   # axis normalised, right-handed
+    t = [1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, -10, 0, -15, 1]                        # as in spheres.json
+    sc = parse_json_scene(J({"transform": [t, [{"sphere": {}}]]}))
+    assert np.allclose(sc.objects[0].xform[:3, 3], [-10, 0, -15])                     # make_mat4: last four = translation
+
+
+def test_material_inherits_from_the_current_top_level_material():
+    sc = parse_json_scene(J(
+        {"material": {"diffuse": {"constant": [0.1, 0.2, 0.3]}, "roughness": 0.25, "index": 1.5}},
+        {"sphere": {}},
+        {"sphere": {"material": {"diffuse": {"constant": [0.9, 0.9, 0.9]}, "metallic": 0.5}}},
+        {"material": {"ambient": {"constant": [1, 1, 1]}}},          # resets, JsonParser.cpp:466-472
+        {"box": {}},
+    ))
+    a, b, c = (sc.materials[o.material] for o in sc.objects)
+    assert np.allclose(a.kd, [0.1, 0.2, 0.3]) and a.roughness == 0.25 and a.index == 1.5 and a.metallic == 0
+    assert np.allclose(b.kd, 0.9) and b.roughness == 0.25 and b.metallic == 0.5
+    assert np.allclose(c.kd, 0) and np.allclose(c.ka, 1) and c.roughness == 1.0 and c.index == 1.0   # material.h:152-158
+
+
+def test_camera_quirks():
+    sc = parse_json_scene(J({"camera": {"position": None, "fov": 30.0}}))                # hitchcockBRDF.json
+    assert np.allclose(sc.camera.eye, 0) and np.allclose(sc.camera.look, [0, 0, -1])
+    sc = parse_json_scene(J({"camera": {"position": [0, 20, -40], "viewdir": [0, -0.6, 1], "updir": [0, 1, 0], "aspectratio": 2.0}}))
+    assert np.allclose(sc.camera.u, [-1, 0, 0])                                          # "aspectratio" is not "aspectRatio": ignored
+    sc = parse_json_scene(J({"camera": {"viewdir": [0, 0, -1], "updir": [0, 1, 0], "aspectRatio": 2.0}}))
+    assert np.allclose(sc.camera.u, [2, 0, 0])
+    with pytest.raises(KeyError):
+        parse_json_scene(J({"camera": {"updir": [0, 1, 0]}}))                            # JsonParser.cpp:73-80
+
+
+def test_lights_and_default_attenuation():
+    sc = parse_json_scene(J(
+        {"point_light": {"position": [1, 2, 3], "color": [1, 1, 1]}},
+        {"rectangle_area_light": {"position": [0, 1, -15], "color": [0, 1, 0], "u": [0, 10, 0], "v": [0, 15, 10], "uL": 5, "vL": 5,
+                                  "quadratic_attenuation_coeff": 0.0008}},
+        {"directional_light": {"direction": [0, -1, 0], "color": [1, 1, 1]}},
+        {"ambient_light": {"color": [0.1, 0.1, 0.1]}}, {"ambient_light": {"color": [0.2, 0.2, 0.2]}},
+    ))
+    assert [L.type for L in sc.lights] == [abi.LIGHT_POINT, abi.LIGHT_RECT_AREA, abi.LIGHT_DIRECTIONAL]
+    assert list(sc.lights[0].atten) == [0, 0, 1]                                         # JsonParser.cpp:144-146
+    assert sc.lights[1].atten[2] == np.float32(0.0008) and sc.lights[1].atten.dtype == np.float32
+    assert np.allclose(sc.ambient, 0.3)                                                  # addAmbient accumulates
+
+
+def test_trimesh_quads_split_and_errors():
+    mesh = {"points": [[0, 0, 0], [1, 0, 0], [1, 1, 0], [0, 1, 0]], "faces": [[0, 1, 2, 3]]}
+    sc = parse_json_scene(J({"tri_mesh": mesh}))
+    assert sc.meshes[0].faces.tolist() == [[0, 1, 2], [0, 2, 3]]                          # JsonParser.cpp:253-257
+    sc = parse_json_scene(J({"tri_mesh": dict(mesh, gennormals=True)}))
+    assert np.allclose(sc.meshes[0].normals, [[0, 0, 1]] * 4)
+    with pytest.raises(ValueError):
+        parse_json_scene(J({"tri_mesh": {"points": [[0, 0, 0]], "faces": [[0, 1, 2]]}}))
+    with pytest.raises(ValueError):
+        parse_json_scene(J({"tri_mesh": dict(mesh, faces=[[0, 1]])}))
+    with pytest.raises(ValueError):
+        parse_json_scene(J({"teapot": {}}))
+    with pytest.raises(NotImplementedError):
+        parse_json_scene(J({"cone": {}}))
+
+
+def test_npz_round_trip(tmp_path, scenes):
+    sc = scenes("hitchcockBRDF")
+    path = tmp_path / "s.npz"
+    sc.save_npz(path)
+    sc2 = Scene.load_npz(path)
+    assert len(sc2.objects) == 141 and len(sc2.lights) == 2
+    assert np.array_equal(sc2.objects[17].xform, sc.objects[17].xform)
+    d1, _k1 = sc.to_c()
+    d2, _k2 = sc2.to_c()
+    assert bytes(d1.camera) == bytes(d2.camera) and d1.n_objects == d2.n_objects
+
+
+def test_fixture_scene_inventory(scenes):
+    # what SURVEY-level inspection of the reference's demo scenes shows
+    s = scenes("spheres")
+    assert len(s.objects) == 37 and sum(o.type == abi.OBJ_SPHERE for o in s.objects) == 36 and s.lights[0].type == abi.LIGHT_RECT_AREA
+    c = scenes("cornellBoxes")
+    assert [o.type for o in c.objects].count(abi.OBJ_SQUARE) == 5 and c.lights[0].type == abi.LIGHT_POINT
+    h = scenes("hitchcockBRDF")
+    assert [o.type for o in h.objects].count(abi.OBJ_BOX) == 140 and len(h.lights) == 2
+    assert len(scenes("singleSphere").lights) == 8
