@@ -206,6 +206,14 @@ def load_library():
             f"{path} is missing: build the HIP library first (make -C path_tracer_amd/csrc). "
             "There is no CPU fallback for the render path."
         )
+    # One HIP runtime per process: PyTorch-ROCm ships its own libamdhip64 and finds no GPU
+    # if another copy initialised the device first, so let torch load its runtime before
+    # libmipt.so resolves the same soname (the host layer uses torch for device buffers,
+    # streams and torch.distributed anyway).
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(path)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported

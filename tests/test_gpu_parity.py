@@ -114,7 +114,7 @@ def test_coincident_spheres_resolve_like_the_reference(gpu, scenes, oracles):
     d /= np.linalg.norm(d, axis=1)[:, None]
     tg, pg, _ = gpu.intersect(np.repeat(eye[None], 6, 0), d)
     to, po, _ = orc.intersect(np.repeat(eye[None], 6, 0), d)
-    assert np.array_equal(pg, po) and np.array_equal(tg, to)
+    assert np.array_equal(pg, po) and np.allclose(tg, to, rtol=1e-12, atol=0)
 
 
 @pytest.mark.parametrize("name", ["spheres", "cornellBoxes", "hitchcockBRDF", "singleSphere", "spheresDirectional"])
