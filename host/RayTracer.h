@@ -1,0 +1,66 @@
+// RayTracer.h — the host-side render driver with the reference's interface
+// (ray/src/RayTracer.h:32-56): loadScene / traceSetup / traceImage / tracePixel /
+// checkRender / waitRender / getBuffer.  The work behind traceImage and tracePixel is
+// done by libmipt through the C ABI of include/mipt.h; this class owns the scene
+// description, the output buffers and the render parameters.
+#ifndef MIPT_HOST_RAYTRACER_H_
+#define MIPT_HOST_RAYTRACER_H_
+
+#include <array>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../include/mipt.h"
+#include "scene_loader.h"
+
+namespace host {
+
+class RayTracer {
+ public:
+  explicit RayTracer(int device = 0);
+  ~RayTracer();
+  RayTracer(const RayTracer &) = delete;
+  RayTracer &operator=(const RayTracer &) = delete;
+
+  // RayTracer.cpp:333-415.  Returns false and keeps the message in lastAlert() on failure
+  // (the reference reports through traceUI->alert).
+  bool loadScene(const char *fn);
+  bool loadScene(SceneData &&scene);
+  bool loadCubemap(const char *dir);  // the `-c` option (TraceUI::smartLoadCubemap)
+  bool sceneLoaded() const { return loaded_; }
+  double aspectRatio() const { return loaded_ ? scene_.camera.getAspectRatio() : 1; }  // RayTracer.cpp:327-330
+
+  void traceSetup(int w, int h);             // RayTracer.cpp:417-442
+  void traceImage(int w, int h);             // RayTracer.cpp:462-491 (returns after the image is complete)
+  std::array<double, 3> tracePixel(int i, int j);  // RayTracer.cpp:59-101
+  bool checkRender() { return true; }        // RayTracer.cpp:503-512
+  void waitRender() {}                       // RayTracer.cpp:514-526
+  void getBuffer(unsigned char *&buf, int &w, int &h);  // RayTracer.cpp:319-324
+  std::array<double, 3> getPixel(int i, int j) const;   // RayTracer.cpp:529-534
+  const std::vector<float> &floatBuffer() const { return buffer_f32_; }
+
+  // The reference's literals (N = 100, q = 0.1, 10 shadow rays, t < 1000) as settings.
+  mipt_params &settings() { return params_; }
+  const std::string &lastAlert() const { return alert_; }
+  bool ok() const { return ctx_ != nullptr; }
+
+ private:
+  bool upload();
+  mipt_ctx *ctx_ = nullptr;
+  SceneData scene_;
+  bool loaded_ = false;
+  std::vector<unsigned char> buffer_;  // w*h*3, index (i + j*w)*3, j = 0 is the bottom row
+  std::vector<float> buffer_f32_;
+  int buffer_width_ = 0, buffer_height_ = 0;
+  mipt_params params_;
+  std::string alert_;
+};
+
+// Image writers (rows flipped on the way out, like fileio/pngimage.cpp:272-273).
+bool write_ppm(const std::string &path, int w, int h, const unsigned char *bottom_up_rgb);
+bool write_png(const std::string &path, int w, int h, const unsigned char *bottom_up_rgb);
+bool write_image(const std::string &path, int w, int h, const unsigned char *bottom_up_rgb);
+
+}  // namespace host
+#endif

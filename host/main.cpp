@@ -1,0 +1,94 @@
+// ray — command-line driver with the reference's calling convention
+// (ui/CommandLineUI.cpp:23-107):  ray [options] scene.json output.{png,ppm}
+//   -w N     image width (default 512, TraceUI.h:96); height = width / aspectRatio
+//   -H N     image height override (the reference can only emit width/aspect)
+//   -j FILE  JSON settings: "size", plus this build's "spp", "rr_q", "area_samples",
+//            "max_depth", "seed" (the reference hard-codes them)
+//   -c DIR   cubemap directory (six P6 files posx/negx/posy/negy/posz/negz.ppm)
+//   -r N     accepted and ignored: the path tracer never reads the recursion depth
+//   -s N     samples per pixel (reference literal: 100)
+//   -d N     HIP device
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <sstream>
+#include <string>
+
+#include "RayTracer.h"
+
+static void usage(const char *prog) {
+  std::fprintf(stderr, "usage: %s [-w width] [-H height] [-s spp] [-j settings.json] [-c cubemap_dir] [-d device] [-r depth] scene.json output.png\n", prog);
+}
+
+int main(int argc, char **argv) {
+  int width = 512, height = 0, spp = -1, device = 0;
+  std::string settings, cubemap;
+  int i = 1;
+  for (; i < argc && argv[i][0] == '-' && argv[i][1] != '\0'; i++) {
+    std::string opt = argv[i];
+    auto need = [&](const char *name) -> const char * {
+      if (i + 1 >= argc) { std::fprintf(stderr, "option %s needs a value\n", name); std::exit(1); }
+      return argv[++i];
+    };
+    if (opt == "-w") width = std::atoi(need("-w"));
+    else if (opt == "-H") height = std::atoi(need("-H"));
+    else if (opt == "-s") spp = std::atoi(need("-s"));
+    else if (opt == "-j") settings = need("-j");
+    else if (opt == "-c") cubemap = need("-c");
+    else if (opt == "-d") device = std::atoi(need("-d"));
+    else if (opt == "-r") (void)need("-r");
+    else if (opt == "-h") { usage(argv[0]); return 0; }
+    else { std::fprintf(stderr, "Invalid argument: '%s'.\n", argv[i]); usage(argv[0]); return 1; }
+  }
+  if (argc - i != 2) { std::fprintf(stderr, "Error: exactly one scene file and one output file are needed\n"); usage(argv[0]); return 1; }
+  const char *rayName = argv[i];
+  const char *imgName = argv[i + 1];
+
+  host::RayTracer rt(device);
+  if (!rt.ok()) { std::fprintf(stderr, "%s\n", rt.lastAlert().c_str()); return 2; }
+  mipt_params &p = rt.settings();
+  if (!settings.empty()) {
+    try {
+      std::ifstream in(settings);
+      std::stringstream ss;
+      ss << in.rdbuf();
+      host::Json j = host::Json::parse(ss.str());
+      if (j.has("size")) width = (int)j.at("size").number();           // TraceUI.cc:44
+      if (j.has("spp")) p.spp = (int)j.at("spp").number();
+      if (j.has("rr_q")) p.rr_q = j.at("rr_q").number();
+      if (j.has("area_samples")) p.area_samples = (int)j.at("area_samples").number();
+      if (j.has("max_depth")) p.max_depth = (int)j.at("max_depth").number();
+      if (j.has("seed")) p.seed = (uint64_t)j.at("seed").number();
+    } catch (const std::exception &e) {
+      std::fprintf(stderr, "settings: %s\n", e.what());
+      return 1;
+    }
+  }
+  if (spp > 0) p.spp = spp;
+  p.sample_begin = 0;
+  p.sample_end = p.spp;
+
+  if (!rt.loadScene(rayName)) {
+    std::fprintf(stderr, "Unable to load ray file '%s': %s\n", rayName, rt.lastAlert().c_str());
+    return 1;
+  }
+  if (!cubemap.empty() && !rt.loadCubemap(cubemap.c_str())) {
+    std::fprintf(stderr, "%s\n", rt.lastAlert().c_str());
+    return 1;
+  }
+  if (height <= 0) height = (int)(width / rt.aspectRatio() + 0.5);  // CommandLineUI.cpp:73-74
+  auto t0 = std::chrono::steady_clock::now();
+  rt.traceSetup(width, height);
+  rt.traceImage(width, height);
+  rt.waitRender();
+  double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  if (!rt.lastAlert().empty()) { std::fprintf(stderr, "render failed: %s\n", rt.lastAlert().c_str()); return 2; }
+  unsigned char *buf;
+  int w, h;
+  rt.getBuffer(buf, w, h);
+  if (!host::write_image(imgName, w, h, buf)) { std::fprintf(stderr, "cannot write %s\n", imgName); return 1; }
+  std::fprintf(stderr, "%dx%d, %d spp: %.3f s, %.2f Msamples/s\n", w, h, p.spp, sec, (double)w * h * p.spp / sec / 1e6);
+  return 0;
+}

@@ -1,0 +1,82 @@
+// scene_loader.h — the host's scene ingest: reads the reference's JSON scene format
+// (parser/JsonParser.cpp, parser/jsonformat.md) into the flat description libmipt takes.
+#ifndef MIPT_HOST_SCENE_LOADER_H_
+#define MIPT_HOST_SCENE_LOADER_H_
+
+#include <array>
+#include <string>
+#include <vector>
+
+#include "../include/mipt.h"
+#include "json.h"
+
+namespace host {
+
+using Vec3 = std::array<double, 3>;
+
+// Column-major 4x4, m[4*c + r] — glm::dmat4 memory order, as mipt_object.xform.
+struct Mat4 {
+  double m[16];
+  static Mat4 identity();
+  static Mat4 translate(const Vec3 &v);
+  static Mat4 scale(const Vec3 &v);
+  static Mat4 rotate(double angle, const Vec3 &axis);  // glm::rotate, radians
+  Mat4 operator*(const Mat4 &o) const;
+};
+
+// scene/camera.{h,cpp}: the camera stays on the host.
+class Camera {
+ public:
+  Camera();
+  void setEye(const Vec3 &e) { eye = e; }
+  void setLook(const Vec3 &viewDir, const Vec3 &upDir);  // camera.cpp:57-67
+  void setFOV(double fovDegrees);                        // camera.cpp:69-75
+  void setAspectRatio(double ar);                        // camera.cpp:77-82
+  double getAspectRatio() const { return aspectRatio; }
+  mipt_camera toAbi() const;
+  Vec3 eye, look, u, v;
+
+ private:
+  void update();  // camera.cpp:84-88
+  double m[9];    // column-major 3x3
+  double normalizedHeight, aspectRatio;
+};
+
+struct MeshData {
+  std::vector<double> vertices;
+  std::vector<int32_t> faces;
+  std::vector<double> normals;
+};
+
+struct SceneData {
+  Camera camera;
+  Vec3 ambient{{0, 0, 0}};
+  std::vector<mipt_material> materials;
+  std::vector<mipt_object> objects;
+  std::vector<MeshData> meshes;
+  std::vector<mipt_light> lights;
+  // cubemap faces (+x,-x,+y,-y,+z,-z), RGB8, row 0 = bottom; empty = none
+  std::vector<uint8_t> cube_rgb[6];
+  int cube_w[6] = {0, 0, 0, 0, 0, 0}, cube_h[6] = {0, 0, 0, 0, 0, 0};
+
+  // Views for mipt_upload_scene; valid while *this is alive and unchanged.
+  mipt_scene_desc describe();
+
+ private:
+  std::vector<mipt_mesh> mesh_views_;
+  mipt_image cube_views_[6];
+};
+
+struct SceneError : std::runtime_error {
+  using std::runtime_error::runtime_error;
+};
+
+// JsonParser::parseScene (JsonParser.cpp:447-515).  Throws SceneError / JsonError.
+SceneData load_scene_file(const std::string &path);
+SceneData parse_scene(const Json &root);
+
+// Six binary PPM (P6) files posx/negx/posy/negy/posz/negz.ppm in `dir` -> cubemap.
+void load_cubemap_ppm(const std::string &dir, SceneData *scene);
+
+}  // namespace host
+#endif
