@@ -167,7 +167,9 @@ LIB_NAME = "libmipt.so"
 
 
 def lib_path() -> str:
-    return os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
+    """libmipt.so next to this file; MIPT_LIB names another build of the same library
+    (kernel tuning experiments)."""
+    return os.environ.get("MIPT_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
 
 
 # name -> (restype, argtypes); every symbol include/mipt.h declares.

@@ -40,6 +40,8 @@ struct mipt_ctx {
   // render workspace
   uint32_t capacity = 0;
   DevBuf queue[2], shade, hits, accum, rows, counts, dcount;
+  DevBuf vis;                // per-shadow-ray results of one chunk of hits
+  int persist_blocks = 1536; // CUs x blocks per CU for the persistent traversal kernels
   DevBuf spill;              // overflow stack of ray records (allocated on first use)
   uint64_t spill_cap = 0;    // entries
   mipt_counters totals{};
@@ -217,8 +219,9 @@ int ensure_spill(mipt_ctx *c, uint64_t used, uint64_t extra, hipStream_t st) {
   return MIPT_OK;
 }
 
-RenderConst make_const(const mipt_params *p, uint32_t capacity) {
+RenderConst make_const(const mipt_ctx *c, const mipt_params *p, uint32_t capacity) {
   RenderConst rc;
+  rc.persist_blocks = c->persist_blocks;
   rc.width = p->width;
   rc.height = p->height;
   rc.area_samples = p->area_samples;
@@ -287,6 +290,9 @@ int mipt_create(mipt_ctx **out, int device) {
   if (!c) return set_err(nullptr, MIPT_ERR_NOMEM, "out of host memory");
   c->device = device;
   std::memset(&c->dev, 0, sizeof(c->dev));
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
+    c->persist_blocks = prop.multiProcessorCount * 6;  // the traversal kernels are built for 6 waves per SIMD
   *out = c;
   return MIPT_OK;
 }
@@ -304,6 +310,7 @@ void mipt_destroy(mipt_ctx *c) {
   release(c->counts);
   release(c->dcount);
   release(c->spill);
+  release(c->vis);
   for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
   delete c;
 }
@@ -405,6 +412,10 @@ int mipt_render_accumulate(mipt_ctx *c, const mipt_params *p, double *d_sum, voi
   if ((r = ensure(c, c->accum, (size_t)batch * 3 * sizeof(double))) != MIPT_OK) return r;
   if ((r = ensure(c, c->rows, rows.size() * sizeof(int))) != MIPT_OK) return r;
   if ((r = ensure(c, c->counts, sizeof(BatchCounts))) != MIPT_OK) return r;
+  // visibility scratch: all shadow rays of a level if they fit 2^27 rays, else chunks of whole hits
+  uint64_t rays_per_hit = (uint64_t)std::max(1, c->dev.rays_per_hit);
+  uint64_t vis_rays = std::max<uint64_t>(std::min<uint64_t>((uint64_t)cap * rays_per_hit, 1ull << 27), rays_per_hit);
+  if ((r = ensure(c, c->vis, vis_rays * sizeof(double) * (c->dev.translucent ? 3 : 1))) != MIPT_OK) return r;
   if (!c->dcount.p) {
     if ((r = ensure(c, c->dcount, sizeof(DeviceCounters))) != MIPT_OK) return r;
     HIP_TRY(c, hipMemset(c->dcount.p, 0, sizeof(DeviceCounters)));
@@ -412,7 +423,7 @@ int mipt_render_accumulate(mipt_ctx *c, const mipt_params *p, double *d_sum, voi
   HIP_TRY(c, hipMemcpyAsync(c->rows.p, rows.data(), rows.size() * sizeof(int), hipMemcpyHostToDevice, st));
   HIP_TRY(c, hipStreamSynchronize(st));  // `rows` is a local vector
 
-  RenderConst rc = make_const(p, cap);
+  RenderConst rc = make_const(c, p, cap);
   RayQueue q[2] = {carve_queue(c->queue[0].p, cap), carve_queue(c->queue[1].p, cap)};
   ShadeList sl = carve_shade(c->shade.p, cap);
   double *hit_t = reinterpret_cast<double *>(c->hits.p);
@@ -459,7 +470,7 @@ int mipt_render_accumulate(mipt_ctx *c, const mipt_params *p, double *d_sum, voi
         }
         if (h.shades) {
           ProfScope ps(c, prof, MIPT_K_SHADOW, (uint64_t)h.shades * (uint64_t)c->dev.rays_per_hit, st);
-          launch_shadow(c->dev, rc, sl, h.shades, accum, dc, count, st);
+          launch_shadow(c->dev, rc, sl, h.shades, reinterpret_cast<double *>(c->vis.p), vis_rays, accum, dc, count, st);
         }
         uint32_t m = h.next_rays;
         cur ^= 1;
@@ -607,7 +618,7 @@ int mipt_shadow_attenuation(mipt_ctx *c, const mipt_params *p, int light, int64_
   if (n == 0) return MIPT_OK;
   HIP_TRY(c, hipSetDevice(c->device));
   if ((r = sync_lights(c, p->area_samples)) != MIPT_OK) return r;
-  RenderConst rc = make_const(p, 0);
+  RenderConst rc = make_const(c, p, 0);
   double *d_f = nullptr, *d_o = nullptr;
   uint64_t *d_k = nullptr;
   size_t v3 = (size_t)n * 3 * sizeof(double);

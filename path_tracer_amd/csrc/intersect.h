@@ -192,49 +192,70 @@ struct TravCounters {
   uint32_t prims;
 };
 
-// Closest hit (ANY = false) or first hit with t < tmax (ANY = true).
-// `stack` points at this lane's first LDS slot; consecutive entries are `stride`
-// words apart (one 4-byte column per lane: conflict-free).
-template <bool ANY, bool COUNT>
-__device__ __forceinline__ Hit traverse(const SceneDev &S, d3 org, d3 dir, double tmax, uint32_t *stack, int stride, TravCounters &tc) {
+// ---- traversal -------------------------------------------------------------------
+// State of one ray's walk through the BVH.  `cur` is the node to visit next: >= 0 an
+// inner node, < 0 a leaf (~cur = first << 3 | count - 1), MIPT_TRAV_DONE when the walk
+// is over.  The stack lives in LDS, one 4-byte column per lane (`stack[k * stride]`).
+#define MIPT_TRAV_DONE ((int)0x80000000)  // ~code of no valid leaf (needs < 2^28 - 1 primitives)
+struct Trav {
+  d3 org, dir;
+  Cull c;
+  float tlimit;
+  int cur, sp;
   Hit best;
-  best.t = tmax;
-  best.prim = -1;
-  Cull c = make_cull(org, dir, S.radius);
-  float tlimit = __double2float_ru(tmax) * 1.0000005f;
-  int sp = 0;
-  int cur = 0;  // root is always an inner node
-  while (true) {
-    if (cur >= 0) {
-      const float4 *np = reinterpret_cast<const float4 *>(S.nodes + cur);
-      float4 q0 = np[0], q1 = np[1], q2 = np[2];
-      int4 q3 = *reinterpret_cast<const int4 *>(np + 3);
-      if (COUNT) tc.nodes++;
-      float lmin[3] = {q0.x, q0.y, q0.z}, lmax[3] = {q0.w, q1.x, q1.y};
-      float rmin[3] = {q1.z, q1.w, q2.x}, rmax[3] = {q2.y, q2.z, q2.w};
-      float tl = slab(c, lmin, lmax, tlimit);
-      float tr = slab(c, rmin, rmax, tlimit);
-      bool hl = tl < 2.0e38f, hr = tr < 2.0e38f;
-      if (hl && hr) {
-        int nearc = q3.x, farc = q3.y;
-        if (tr < tl) { nearc = q3.y; farc = q3.x; }
-        stack[sp * stride] = (uint32_t)farc;
-        sp++;
-        cur = nearc;
-      } else if (hl) {
-        cur = q3.x;
-      } else if (hr) {
-        cur = q3.y;
-      } else {
-        if (sp == 0) break;
-        sp--;
-        cur = (int)stack[sp * stride];
-      }
-      continue;
+};
+
+__device__ __forceinline__ void trav_init(Trav &T, const SceneDev &S, d3 org, d3 dir, double tmax) {
+  T.org = org;
+  T.dir = dir;
+  T.c = make_cull(org, dir, S.radius);
+  T.tlimit = __double2float_ru(tmax) * 1.0000005f;
+  T.cur = 0;  // the root is always an inner node
+  T.sp = 0;
+  T.best.t = tmax;
+  T.best.prim = -1;
+}
+
+// One round of the "while-while" walk: descend through inner nodes until the lane holds a
+// leaf (or is done), then test that leaf's primitives and pop the next node.  Keeping the
+// two phases apart lets the lanes of a wave run the fp64 primitive tests together instead
+// of paying for both bodies on every iteration.
+// Closest hit (ANY = false): keeps the smallest (t, ref_order).  Any hit (ANY = true): the
+// first primitive found with t < tmax ends the walk.
+template <bool ANY, bool COUNT>
+__device__ __forceinline__ void trav_round(Trav &T, const SceneDev &S, uint32_t *stack, int stride, TravCounters &tc) {
+  int cur = T.cur, sp = T.sp;
+  while (cur >= 0) {
+    const float4 *np = reinterpret_cast<const float4 *>(S.nodes + cur);
+    float4 q0 = np[0], q1 = np[1], q2 = np[2];
+    int4 q3 = *reinterpret_cast<const int4 *>(np + 3);
+    if (COUNT) tc.nodes++;
+    float lmin[3] = {q0.x, q0.y, q0.z}, lmax[3] = {q0.w, q1.x, q1.y};
+    float rmin[3] = {q1.z, q1.w, q2.x}, rmax[3] = {q2.y, q2.z, q2.w};
+    float tl = slab(T.c, lmin, lmax, T.tlimit);
+    float tr = slab(T.c, rmin, rmax, T.tlimit);
+    bool hl = tl < 2.0e38f, hr = tr < 2.0e38f;
+    if (hl && hr) {
+      int nearc = q3.x, farc = q3.y;
+      if (tr < tl) { nearc = q3.y; farc = q3.x; }
+      stack[sp * stride] = (uint32_t)farc;
+      sp++;
+      cur = nearc;
+    } else if (hl) {
+      cur = q3.x;
+    } else if (hr) {
+      cur = q3.y;
+    } else if (sp == 0) {
+      cur = MIPT_TRAV_DONE;
+    } else {
+      sp--;
+      cur = (int)stack[sp * stride];
     }
-    // leaf
+  }
+  if (cur != MIPT_TRAV_DONE) {
     uint32_t code = (uint32_t)~cur;
     uint32_t first = code >> 3, count = (code & 7u) + 1u;
+    bool found = false;
     for (uint32_t k = 0; k < count; k++) {
       uint32_t s = first + k;
       uint32_t info = S.prim_info[s];
@@ -244,27 +265,40 @@ __device__ __forceinline__ Hit traverse(const SceneDev &S, d3 org, d3 dir, doubl
       if (COUNT) tc.prims++;
       if (kind == KIND_TRI) {
         double w1, w2;
-        hit = tri_hit(S.tris + s, org, dir, t, w1, w2);
+        hit = tri_hit(S.tris + s, T.org, T.dir, t, w1, w2);
       } else {
         d3 Nl;
-        hit = analytic_hit(S.objects + (info & 0x3fffffffu), kind, org, dir, t, Nl);
+        hit = analytic_hit(S.objects + (info & 0x3fffffffu), kind, T.org, T.dir, t, Nl);
       }
       if (hit) {
-        bool closer = t < best.t;
-        if (!ANY && t == best.t && best.prim >= 0) closer = S.ref_order[s] < S.ref_order[best.prim];
+        bool closer = t < T.best.t;
+        if (!ANY && t == T.best.t && T.best.prim >= 0) closer = S.ref_order[s] < S.ref_order[T.best.prim];
         if (closer) {
-          best.t = t;
-          best.prim = (int)s;
-          if (ANY) return best;
-          tlimit = __double2float_ru(t) * 1.0000005f;
+          T.best.t = t;
+          T.best.prim = (int)s;
+          T.tlimit = __double2float_ru(t) * 1.0000005f;
+          if (ANY) { found = true; break; }
         }
       }
     }
-    if (sp == 0) break;
-    sp--;
-    cur = (int)stack[sp * stride];
+    if (found || sp == 0) {
+      cur = MIPT_TRAV_DONE;
+    } else {
+      sp--;
+      cur = (int)stack[sp * stride];
+    }
   }
-  return best;
+  T.cur = cur;
+  T.sp = sp;
+}
+
+// The whole walk of one ray.
+template <bool ANY, bool COUNT>
+__device__ __forceinline__ Hit traverse(const SceneDev &S, d3 org, d3 dir, double tmax, uint32_t *stack, int stride, TravCounters &tc) {
+  Trav T;
+  trav_init(T, S, org, dir, tmax);
+  while (T.cur != MIPT_TRAV_DONE) trav_round<ANY, COUNT>(T, S, stack, stride, tc);
+  return T.best;
 }
 
 // World-space unit normal of a hit, as isect::getN() holds it after

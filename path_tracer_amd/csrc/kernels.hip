@@ -24,6 +24,9 @@
 namespace mipt {
 
 constexpr int kBlock = 256;
+#ifndef MIPT_TRAV_WAVES
+#define MIPT_TRAV_WAVES 4  // waves per SIMD the traversal kernels are compiled for
+#endif
 
 // ------------------------------------------------------------------ helpers ----
 __device__ __forceinline__ uint32_t lane_id() { return __lane_id(); }
@@ -140,18 +143,66 @@ __global__ void __launch_bounds__(kBlock) k_generate(SceneDev S, RenderConst rc,
 }
 
 // --------------------------------------------------------------- intersect ----
+// Persistent waves with ray replacement.  Rays differ wildly in how many nodes they
+// visit, and a wave lasts as long as its slowest lane; so a lane whose ray is finished
+// does not wait for the others: once kRefillIdle lanes of a wave are idle they are given
+// new rays.  Every wave owns a fixed, interleaved sequence of 64-ray chunks (chunk
+// numbers wave, wave + W, wave + 2W, ...), so there is no work counter to contend for and
+// rays that are neighbours in the queue still enter a wave together.
+#ifndef MIPT_REFILL_IDLE
+#define MIPT_REFILL_IDLE 20
+#endif
+constexpr uint32_t kRefillIdle = MIPT_REFILL_IDLE;
+
+__device__ __forceinline__ uint64_t wave_seq_item(uint32_t i, uint32_t wave, uint32_t n_waves) {
+  return ((uint64_t)(i >> 6) * n_waves + wave) * 64ull + (i & 63u);
+}
+__device__ __forceinline__ uint32_t rank_below(unsigned long long mask, uint32_t lane) {
+  return (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+}
+
 template <bool COUNT>
-__global__ void __launch_bounds__(kBlock) k_intersect(SceneDev S, RenderConst rc, RayQueue q, uint32_t n, double *__restrict__ hit_t,
-                                                       int *__restrict__ hit_prim, DeviceCounters *dc) {
+__global__ void __launch_bounds__(kBlock, MIPT_TRAV_WAVES) k_intersect(SceneDev S, RenderConst rc, RayQueue q, uint32_t n, double *__restrict__ hit_t,
+                                                                        int *__restrict__ hit_prim, DeviceCounters *dc) {
   extern __shared__ uint32_t lds_stack[];
-  uint32_t idx = blockIdx.x * kBlock + threadIdx.x;
+  uint32_t *stack = lds_stack + threadIdx.x;
+  const uint32_t lane = lane_id();
+  const uint32_t wave = blockIdx.x * (kBlock / 64) + threadIdx.x / 64;
+  const uint32_t n_waves = gridDim.x * (kBlock / 64);
   TravCounters tc{0, 0};
-  if (idx < n) {
-    d3 o{q.ox[idx], q.oy[idx], q.oz[idx]};
-    d3 d{q.dx[idx], q.dy[idx], q.dz[idx]};
-    Hit h = traverse<false, COUNT>(S, o, d, rc.t_max, lds_stack + threadIdx.x, kBlock, tc);
-    hit_t[idx] = h.t;
-    hit_prim[idx] = h.prim;
+  Trav T;
+  T.cur = MIPT_TRAV_DONE;
+  T.sp = 0;
+  bool idle = true;
+  uint32_t ray = 0;
+  uint32_t next = 0;                                      // position in this wave's sequence (wave-uniform)
+  bool exhausted = wave_seq_item(0, wave, n_waves) >= n;  // wave-uniform
+  while (true) {
+    unsigned long long idle_mask = __ballot(idle);
+    if (idle_mask != 0ull && !exhausted) {
+      if (idle) {
+        uint64_t item = wave_seq_item(next + rank_below(idle_mask, lane), wave, n_waves);
+        if (item < n) {
+          ray = (uint32_t)item;
+          d3 o{q.ox[ray], q.oy[ray], q.oz[ray]};
+          d3 d{q.dx[ray], q.dy[ray], q.dz[ray]};
+          trav_init(T, S, o, d, rc.t_max);
+          idle = false;
+        }
+      }
+      next += (uint32_t)__popcll(idle_mask);
+      exhausted = wave_seq_item(next, wave, n_waves) >= n;
+    }
+    if (__ballot(!idle) == 0ull) break;
+    const uint32_t want_idle = exhausted ? 64u : kRefillIdle;
+    do {
+      trav_round<false, COUNT>(T, S, stack, kBlock, tc);
+      if (!idle && T.cur == MIPT_TRAV_DONE) {
+        hit_t[ray] = T.best.t;
+        hit_prim[ray] = T.best.prim;
+        idle = true;
+      }
+    } while ((uint32_t)__popcll(__ballot(idle)) < want_idle);
   }
   if (COUNT) {
     wave_count(&dc->closest_nodes, tc.nodes);
@@ -330,24 +381,27 @@ __device__ d3 shadow_walk(const SceneDev &S, d3 light, d3 p, d3 d, bool has_targ
   return light;
 }
 
-// One shadow ray of light `L` for the shading point with firePos `fire`:
-// sample `s` of an area light (including its min(1, 1/denom), excluding the 1/S),
-// or the single ray of a point / directional light.
-template <bool COUNT, bool WALK>
-__device__ d3 shadow_ray(const SceneDev &S, const RenderConst &rc, const LightRec &L, int li, int s, d3 fire, uint64_t key,
-                         uint32_t *stack, int stride, TravCounters &tc) {
-  d3 color = ld3(L.color);
-  d3 dir, target{0, 0, 0};
-  double lightT = rc.t_max;
-  bool has_target = true;
-  double scale = 1.0;
+// Geometry of one shadow ray of light `L` from firePos `fire`: sample `s` of an area light
+// or the single ray of a point / directional light.  `scale` is the area sample's
+// min(1, 1/denom) (light.cpp:139-142), 1 otherwise.
+struct ShadowSetup {
+  d3 dir, target;
+  double lightT, scale;
+  bool has_target;
+};
+__device__ __forceinline__ ShadowSetup shadow_setup(const RenderConst &rc, const LightRec &L, int li, int s, d3 fire, uint64_t key) {
+  ShadowSetup r;
+  r.target = d3{0, 0, 0};
+  r.lightT = rc.t_max;
+  r.has_target = true;
+  r.scale = 1.0;
   if (L.type == MIPT_LIGHT_DIRECTIONAL) {  // light.cpp:15-35
-    dir = -ld3(L.orientation);
-    has_target = false;
+    r.dir = -ld3(L.orientation);
+    r.has_target = false;
   } else if (L.type == MIPT_LIGHT_POINT) {  // light.cpp:63-85
-    target = ld3(L.position);
-    dir = normalize(target - fire);
-    lightT = sqrt(dot(target - fire, target - fire));
+    r.target = ld3(L.position);
+    r.dir = normalize(r.target - fire);
+    r.lightT = sqrt(dot(r.target - fire, r.target - fire));
   } else {  // light.cpp:105-147
     double uI, vI;
     if (rc.flags & MIPT_FLAG_FIXED_AREA_PATTERN) {
@@ -360,71 +414,162 @@ __device__ d3 shadow_ray(const SceneDev &S, const RenderConst &rc, const LightRe
     }
     // samplePoint: corner + uVec*uI + vVec + vI — vVec whole, vI on every component (light.cpp:109)
     d3 cu = (ld3(L.position) + ld3(L.u) * uI) + ld3(L.v);
-    target = d3{cu.x + vI, cu.y + vI, cu.z + vI};
-    dir = normalize(target - fire);
-    lightT = sqrt(dot(target - fire, target - fire));
-    double dd = length(fire - target);
+    r.target = d3{cu.x + vI, cu.y + vI, cu.z + vI};
+    r.dir = normalize(r.target - fire);
+    r.lightT = sqrt(dot(r.target - fire, r.target - fire));
+    double dd = length(fire - r.target);
     double denom = L.a + L.b * dd + L.c * (dd * dd);
-    scale = fmin(1.0, 1 / denom);
+    r.scale = fmin(1.0, 1 / denom);
   }
+  return r;
+}
+
+// One whole shadow ray (test hook and the translucent kernel): Light::shadowAttenuation's
+// per-ray value, area 1/S excluded.
+template <bool COUNT, bool WALK>
+__device__ d3 shadow_ray(const SceneDev &S, const RenderConst &rc, const LightRec &L, int li, int s, d3 fire, uint64_t key,
+                         uint32_t *stack, int stride, TravCounters &tc) {
+  ShadowSetup su = shadow_setup(rc, L, li, s, fire, key);
+  d3 color = ld3(L.color);
   d3 light;
   if (WALK) {
-    light = shadow_walk<COUNT>(S, color, fire, dir, has_target, target, lightT, rc.t_max, stack, stride, tc);
+    light = shadow_walk<COUNT>(S, color, fire, su.dir, su.has_target, su.target, su.lightT, rc.t_max, stack, stride, tc);
   } else {
     // every kt is 0: the walk multiplies by pow(0, dist > 0) = 0 on the first occluder,
     // so "any hit closer than the light" decides it
-    double lim = fmin(lightT, rc.t_max);
-    Hit h = traverse<true, COUNT>(S, fire, dir, lim, stack, stride, tc);
+    Hit h = traverse<true, COUNT>(S, fire, su.dir, fmin(su.lightT, rc.t_max), stack, stride, tc);
     light = h.prim >= 0 ? d3{0, 0, 0} : color;
   }
-  return light * scale;
+  return light * su.scale;
 }
 
-template <bool COUNT, bool WALK>
-__global__ void __launch_bounds__(kBlock) k_shadow(SceneDev S, RenderConst rc, ShadeList sl, uint32_t n_shades, uint64_t first_item,
-                                                    uint64_t n_items, double *accum, DeviceCounters *dc) {
+// Shadow ray `r` of a hit belongs to the light whose block of rays contains it.
+__device__ __forceinline__ int light_of_ray(const SceneDev &S, uint32_t r) {
+  int li = 0;
+  for (int k = 1; k < S.n_lights; k++)
+    if ((uint32_t)S.lights[k].first_ray <= r) li = k;
+  return li;
+}
+
+// Any-hit shadow rays for opaque scenes, persistent waves with ray replacement (see
+// k_intersect).  Work item w = hit * rays_per_hit + ray: the rays of one hit are adjacent
+// and enter a wave together, so they share origin and target region.  Result per ray:
+// vis[w - first_item] = 0 if occluded, else the sample's attenuation scale.
+template <bool COUNT>
+__global__ void __launch_bounds__(kBlock, MIPT_TRAV_WAVES) k_shadow_any(SceneDev S, RenderConst rc, ShadeList sl, uint64_t first_item, uint32_t n_items,
+                                                                         double *__restrict__ vis, DeviceCounters *dc) {
   extern __shared__ uint32_t lds_stack[];
-  uint64_t w = first_item + (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  uint32_t *stack = lds_stack + threadIdx.x;
+  const uint32_t lane = lane_id();
+  const uint32_t wave = blockIdx.x * (kBlock / 64) + threadIdx.x / 64;
+  const uint32_t n_waves = gridDim.x * (kBlock / 64);
+  const uint32_t R = (uint32_t)S.rays_per_hit;
   TravCounters tc{0, 0};
-  d3 v{0, 0, 0};
-  uint32_t h = 0xffffffffu;
-  uint32_t slot = 0;
-  uint32_t R = (uint32_t)S.rays_per_hit;
-  if (w < first_item + n_items) {
-    h = (uint32_t)(w / R);
-    uint32_t r = (uint32_t)(w - (uint64_t)h * R);
-    // light and sample of ray r: lights own consecutive blocks of rays
-    int li = 0;
-    for (int k = 1; k < S.n_lights; k++)
-      if ((uint32_t)S.lights[k].first_ray <= r) li = k;
-    const LightRec &L = S.lights[li];
-    int s = (int)r - L.first_ray;
-    d3 P{sl.px[h], sl.py[h], sl.pz[h]};
-    d3 N{sl.nx[h], sl.ny[h], sl.nz[h]};
-    d3 Wt{sl.wx[h], sl.wy[h], sl.wz[h]};
-    uint64_t key = sl.key[h];
-    slot = sl.slot[h];
-    d3 fire = P + (N * MIPT_RAY_EPSILON) * 3.0;  // material.cpp:117
-    d3 light = shadow_ray<COUNT, WALK>(S, rc, L, li, s, fire, key, lds_stack + threadIdx.x, kBlock, tc);
-    // diffuse term, material.cpp:123-128: shadow * distAtten(P) * kd * |n.L(P)| / pi * (1 - metallic)
-    double f = distance_attenuation(L, P) * fabs(dot(N, light_direction(L, P)));
-    if (L.type == MIPT_LIGHT_RECT_AREA) f = f / (double)L.samples;  // light.cpp:145
-    v = (light * Wt) * f;
+  Trav T;
+  T.cur = MIPT_TRAV_DONE;
+  T.sp = 0;
+  bool idle = true;
+  uint32_t item = 0;
+  double scale = 0.0;
+  uint32_t next = 0;
+  bool exhausted = wave_seq_item(0, wave, n_waves) >= n_items;
+  while (true) {
+    unsigned long long idle_mask = __ballot(idle);
+    if (idle_mask != 0ull && !exhausted) {
+      if (idle) {
+        uint64_t it = wave_seq_item(next + rank_below(idle_mask, lane), wave, n_waves);
+        if (it < n_items) {
+          item = (uint32_t)it;
+          uint64_t w = first_item + it;
+          uint32_t h = (uint32_t)(w / R);
+          uint32_t r = (uint32_t)(w - (uint64_t)h * R);
+          int li = light_of_ray(S, r);
+          const LightRec &L = S.lights[li];
+          d3 P{sl.px[h], sl.py[h], sl.pz[h]};
+          d3 N{sl.nx[h], sl.ny[h], sl.nz[h]};
+          d3 fire = P + (N * MIPT_RAY_EPSILON) * 3.0;  // material.cpp:117
+          ShadowSetup su = shadow_setup(rc, L, li, (int)r - L.first_ray, fire, sl.key[h]);
+          scale = su.scale;
+          trav_init(T, S, fire, su.dir, fmin(su.lightT, rc.t_max));
+          idle = false;
+        }
+      }
+      next += (uint32_t)__popcll(idle_mask);
+      exhausted = wave_seq_item(next, wave, n_waves) >= n_items;
+    }
+    if (__ballot(!idle) == 0ull) break;
+    const uint32_t want_idle = exhausted ? 64u : kRefillIdle;
+    do {
+      trav_round<true, COUNT>(T, S, stack, kBlock, tc);
+      if (!idle && T.cur == MIPT_TRAV_DONE) {
+        vis[item] = T.best.prim >= 0 ? 0.0 : scale;
+        idle = true;
+      }
+    } while ((uint32_t)__popcll(__ballot(idle)) < want_idle);
   }
-  // segmented sum over the lanes that share a hit (they are contiguous)
-  uint32_t lane = lane_id();
-  for (int off = 1; off < 64; off <<= 1) {
-    double ox = __shfl_down(v.x, off), oy = __shfl_down(v.y, off), oz = __shfl_down(v.z, off);
-    uint32_t oh = __shfl_down(h, off);
-    if (lane + off < 64 && oh == h) { v.x += ox; v.y += oy; v.z += oz; }
-  }
-  uint32_t ph = __shfl_up(h, 1);
-  bool head = (lane == 0) || (ph != h);
-  if (head && h != 0xffffffffu) deposit(accum, slot, v);
   if (COUNT) {
     wave_count(&dc->shadow_nodes, tc.nodes);
     wave_count(&dc->shadow_prims, tc.prims);
   }
+}
+
+// Translucent scenes: the full occluder walk, one lane per ray; vis3 holds the walk's colour
+// times the sample scale.
+template <bool COUNT>
+__global__ void __launch_bounds__(kBlock, 2) k_shadow_walk(SceneDev S, RenderConst rc, ShadeList sl, uint64_t first_item, uint32_t n_items,
+                                                            double *__restrict__ vis3, DeviceCounters *dc) {
+  extern __shared__ uint32_t lds_stack[];
+  uint32_t it = blockIdx.x * kBlock + threadIdx.x;
+  TravCounters tc{0, 0};
+  if (it < n_items) {
+    const uint32_t R = (uint32_t)S.rays_per_hit;
+    uint64_t w = first_item + it;
+    uint32_t h = (uint32_t)(w / R);
+    uint32_t r = (uint32_t)(w - (uint64_t)h * R);
+    int li = light_of_ray(S, r);
+    const LightRec &L = S.lights[li];
+    d3 P{sl.px[h], sl.py[h], sl.pz[h]};
+    d3 N{sl.nx[h], sl.ny[h], sl.nz[h]};
+    d3 fire = P + (N * MIPT_RAY_EPSILON) * 3.0;
+    d3 light = shadow_ray<COUNT, true>(S, rc, L, li, (int)r - L.first_ray, fire, sl.key[h], lds_stack + threadIdx.x, kBlock, tc);
+    vis3[3ull * it + 0] = light.x;
+    vis3[3ull * it + 1] = light.y;
+    vis3[3ull * it + 2] = light.z;
+  }
+  if (COUNT) {
+    wave_count(&dc->shadow_nodes, tc.nodes);
+    wave_count(&dc->shadow_prims, tc.prims);
+  }
+}
+
+// Direct diffuse term of one shaded hit from its shadow-ray results (material.cpp:111-130):
+// sum over lights of shadowAttenuation * distAtten(P) * kd * |n.L(P)| / pi * (1 - metallic),
+// added to the sample accumulator with the hit's throughput (folded into W).
+template <bool WALK>
+__global__ void __launch_bounds__(kBlock) k_shadow_sum(SceneDev S, ShadeList sl, uint32_t first_hit, uint32_t n_hits, const double *__restrict__ vis,
+                                                        double *accum) {
+  uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n_hits) return;
+  uint32_t h = first_hit + i;
+  const uint32_t R = (uint32_t)S.rays_per_hit;
+  d3 P{sl.px[h], sl.py[h], sl.pz[h]};
+  d3 N{sl.nx[h], sl.ny[h], sl.nz[h]};
+  d3 Wt{sl.wx[h], sl.wy[h], sl.wz[h]};
+  const double *v = vis + (WALK ? 3ull : 1ull) * (uint64_t)i * R;
+  d3 total{0, 0, 0};
+  for (int li = 0; li < S.n_lights; li++) {
+    const LightRec &L = S.lights[li];
+    d3 sum{0, 0, 0};
+    for (int s = 0; s < L.samples; s++) {
+      uint32_t r = (uint32_t)(L.first_ray + s);
+      if (WALK) sum = sum + d3{v[3 * r], v[3 * r + 1], v[3 * r + 2]};
+      else sum = sum + ld3(L.color) * v[r];
+    }
+    if (L.type == MIPT_LIGHT_RECT_AREA) sum = sum / (double)L.samples;  // light.cpp:145
+    double f = distance_attenuation(L, P) * fabs(dot(N, light_direction(L, P)));
+    total = total + (sum * f) * Wt;
+  }
+  deposit(accum, sl.slot[h], total);
 }
 
 // ----------------------------------------------------------------- resolve ----
@@ -512,13 +657,21 @@ void launch_generate(const SceneDev &S, const RenderConst &rc, const int *rows, 
   hipLaunchKernelGGL(k_generate, dim3(grid_for(total)), dim3(kBlock), 0, st, S, rc, rows, first_pixel, n_pixels, sample0, n_samples, q);
 }
 
+// Grid of a persistent traversal kernel: enough blocks to fill every CU at the compiled
+// occupancy, fewer when there is less work than that.
+static inline unsigned persistent_grid(const RenderConst &rc, uint64_t n) {
+  uint64_t full = (n + kBlock - 1) / kBlock;
+  uint64_t cap = (uint64_t)rc.persist_blocks;
+  return (unsigned)(full < cap ? full : cap);
+}
+
 void launch_intersect(const SceneDev &S, const RenderConst &rc, RayQueue q, uint32_t n, double *hit_t, int *hit_prim, DeviceCounters *dc,
                       bool count, hipStream_t st) {
   if (!n) return;
   if (count)
-    hipLaunchKernelGGL(k_intersect<true>, dim3(grid_for(n)), dim3(kBlock), stack_bytes(S), st, S, rc, q, n, hit_t, hit_prim, dc);
+    hipLaunchKernelGGL(k_intersect<true>, dim3(persistent_grid(rc, n)), dim3(kBlock), stack_bytes(S), st, S, rc, q, n, hit_t, hit_prim, dc);
   else
-    hipLaunchKernelGGL(k_intersect<false>, dim3(grid_for(n)), dim3(kBlock), stack_bytes(S), st, S, rc, q, n, hit_t, hit_prim, dc);
+    hipLaunchKernelGGL(k_intersect<false>, dim3(persistent_grid(rc, n)), dim3(kBlock), stack_bytes(S), st, S, rc, q, n, hit_t, hit_prim, dc);
 }
 
 void launch_shade(const SceneDev &S, const RenderConst &rc, RayQueue q, uint32_t n, const double *hit_t, const int *hit_prim,
@@ -547,17 +700,25 @@ void launch_copy_rays(RayQueue src, uint64_t src_off, RayQueue dst, uint64_t dst
   hipLaunchKernelGGL(k_copy_rays, dim3(grid_for(n)), dim3(kBlock), 0, st, src, src_off, dst, dst_off, n);
 }
 
-void launch_shadow(const SceneDev &S, const RenderConst &rc, ShadeList sl, uint32_t n_shades, double *accum, DeviceCounters *dc, bool count,
-                   hipStream_t st) {
-  uint64_t items = (uint64_t)n_shades * (uint64_t)S.rays_per_hit;
-  if (!items) return;
-  // launches of at most 2^30 lanes; each starts on a hit boundary (a multiple of
-  // rays_per_hit) so no hit is split across launches
-  uint64_t per = ((1ull << 30) / (uint64_t)S.rays_per_hit) * (uint64_t)S.rays_per_hit;
-  for (uint64_t first = 0; first < items; first += per) {
-    uint64_t cnt = items - first < per ? items - first : per;
-    auto kern = S.translucent ? (count ? k_shadow<true, true> : k_shadow<false, true>) : (count ? k_shadow<true, false> : k_shadow<false, false>);
-    hipLaunchKernelGGL(kern, dim3(grid_for(cnt)), dim3(kBlock), stack_bytes(S), st, S, rc, sl, n_shades, first, cnt, accum, dc);
+void launch_shadow(const SceneDev &S, const RenderConst &rc, ShadeList sl, uint32_t n_shades, double *vis, uint64_t vis_rays, double *accum,
+                   DeviceCounters *dc, bool count, hipStream_t st) {
+  if (!n_shades || !S.rays_per_hit) return;
+  // chunks of whole hits whose rays fit the visibility buffer
+  uint64_t R = (uint64_t)S.rays_per_hit;
+  uint64_t hits_per = vis_rays / R;
+  if (hits_per == 0) return;
+  for (uint64_t h0 = 0; h0 < n_shades; h0 += hits_per) {
+    uint32_t nh = (uint32_t)((n_shades - h0 < hits_per) ? n_shades - h0 : hits_per);
+    uint32_t items = (uint32_t)(nh * R);
+    if (S.translucent) {
+      auto kern = count ? k_shadow_walk<true> : k_shadow_walk<false>;
+      hipLaunchKernelGGL(kern, dim3(grid_for(items)), dim3(kBlock), stack_bytes(S), st, S, rc, sl, h0 * R, items, vis, dc);
+      hipLaunchKernelGGL(k_shadow_sum<true>, dim3(grid_for(nh)), dim3(kBlock), 0, st, S, sl, (uint32_t)h0, nh, vis, accum);
+    } else {
+      auto kern = count ? k_shadow_any<true> : k_shadow_any<false>;
+      hipLaunchKernelGGL(kern, dim3(persistent_grid(rc, items)), dim3(kBlock), stack_bytes(S), st, S, rc, sl, h0 * R, items, vis, dc);
+      hipLaunchKernelGGL(k_shadow_sum<false>, dim3(grid_for(nh)), dim3(kBlock), 0, st, S, sl, (uint32_t)h0, nh, vis, accum);
+    }
   }
 }
 
