@@ -201,7 +201,7 @@ def main():
         achieved = (bytes_step / max(1.0, launches_step)) / (avg_launch_ms * 1e-3) / 1e9 if kt["launches"] else 0.0
         roofline = {
             "bound": "hbm",
-            "kernel": "k_" + dominant,
+            "kernel": "k_shadow_any" if dominant == "shadow" else "k_intersect",
             "achieved": achieved,
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
@@ -283,7 +283,7 @@ def load_traffic(workload, kernel):
     try:
         with open(path) as fh:
             t = json.load(fh)
-        return t.get(workload, {}).get("k_" + kernel, {}).get("hbm_bytes_per_launch")
+        return t.get(workload, {}).get("k_shadow_any" if kernel == "shadow" else "k_intersect", {}).get("hbm_bytes_per_launch")
     except (OSError, ValueError):
         return None
 

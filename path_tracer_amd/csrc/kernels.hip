@@ -31,18 +31,40 @@ constexpr int kBlock = 256;
 // ------------------------------------------------------------------ helpers ----
 __device__ __forceinline__ uint32_t lane_id() { return __lane_id(); }
 
-// Wave-aggregated append: every lane of the wave must call it.
-__device__ __forceinline__ uint32_t wave_append(bool active, uint32_t *counter) {
-  unsigned long long mask = __ballot(active);
-  uint32_t lane = lane_id();
-  uint32_t base = 0;
-  if (mask != 0ull) {
-    int leader = __ffsll((long long)mask) - 1;
-    if ((int)lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(mask));
-    base = __shfl(base, leader);
+// Block-aggregated append of up to three output streams: every thread of the block calls it
+// once.  Each wave counts its emitters with ballots, the block's first thread reserves
+// space with ONE atomic per counter (a single word takes only ~90 atomics per microsecond,
+// so per-wave atomics on the queue counters would bound the whole kernel), and every
+// emitter gets base + waves-before + lanes-before.  Streams a and b share counter `ca`.
+template <int BLOCK>
+__device__ __forceinline__ void block_append3(bool a, bool b, bool c, uint32_t *ca, uint32_t *cc, uint32_t &ia, uint32_t &ib, uint32_t &ic) {
+  constexpr int W = BLOCK / 64;
+  __shared__ uint32_t cnt[3][W];
+  __shared__ uint32_t base[2];
+  const uint32_t lane = lane_id(), w = threadIdx.x / 64;
+  unsigned long long ma = __ballot(a), mb = __ballot(b), mc = __ballot(c);
+  if (lane == 0) {
+    cnt[0][w] = (uint32_t)__popcll(ma);
+    cnt[1][w] = (uint32_t)__popcll(mb);
+    cnt[2][w] = (uint32_t)__popcll(mc);
   }
-  unsigned long long below = mask & ((1ull << lane) - 1ull);
-  return base + (uint32_t)__popcll(below);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t ta = 0, tb = 0, tc = 0;
+    for (int k = 0; k < W; k++) {
+      uint32_t x = cnt[0][k]; cnt[0][k] = ta; ta += x;
+      uint32_t y = cnt[1][k]; cnt[1][k] = tb; tb += y;
+      uint32_t z = cnt[2][k]; cnt[2][k] = tc; tc += z;
+    }
+    for (int k = 0; k < W; k++) cnt[1][k] += ta;  // stream b follows stream a in the shared region
+    base[0] = (ta + tb) ? atomicAdd(ca, ta + tb) : 0u;
+    base[1] = tc ? atomicAdd(cc, tc) : 0u;
+  }
+  __syncthreads();
+  unsigned long long below = (1ull << lane) - 1ull;
+  ia = base[0] + cnt[0][w] + (uint32_t)__popcll(ma & below);
+  ib = base[0] + cnt[1][w] + (uint32_t)__popcll(mb & below);
+  ic = base[1] + cnt[2][w] + (uint32_t)__popcll(mc & below);
 }
 
 __device__ __forceinline__ void wave_count(unsigned long long *dst, uint32_t v) {
@@ -211,11 +233,15 @@ __global__ void __launch_bounds__(kBlock, MIPT_TRAV_WAVES) k_intersect(SceneDev 
 }
 
 // ------------------------------------------------------------------- shade ----
+#ifndef MIPT_SHADE_BLOCK
+#define MIPT_SHADE_BLOCK 512
+#endif
+constexpr int kShadeBlock = MIPT_SHADE_BLOCK;
 template <bool COUNT>
-__global__ void __launch_bounds__(kBlock) k_shade(SceneDev S, RenderConst rc, RayQueue q, uint32_t n, const double *__restrict__ hit_t,
+__global__ void __launch_bounds__(kShadeBlock) k_shade(SceneDev S, RenderConst rc, RayQueue q, uint32_t n, const double *__restrict__ hit_t,
                                                    const int *__restrict__ hit_prim, RayQueue nq, ShadeList sl, BatchCounts *bc,
                                                    double *accum, DeviceCounters *dc) {
-  uint32_t idx = blockIdx.x * kBlock + threadIdx.x;
+  uint32_t idx = blockIdx.x * kShadeBlock + threadIdx.x;
   bool live = idx < n;
   bool emitBounce = false, emitMirror = false, emitShade = false;
   d3 P{0, 0, 0}, N{0, 0, 0}, W{0, 0, 0}, wdir{0, 0, 0}, rdir{0, 0, 0}, Tb{0, 0, 0}, Tm{0, 0, 0};
@@ -310,10 +336,9 @@ __global__ void __launch_bounds__(kBlock) k_shade(SceneDev S, RenderConst rc, Ra
       }
     }
   }
-  // ---- compaction: ballot + one atomic per wave and stream --------------------
-  uint32_t ib = wave_append(emitBounce, &bc->next_rays);
-  uint32_t im = wave_append(emitMirror, &bc->next_rays);
-  uint32_t is = wave_append(emitShade, &bc->shades);
+  // ---- compaction: ballots per wave, one atomic per block and counter -----------
+  uint32_t ib, im, is;
+  block_append3<kShadeBlock>(emitBounce, emitMirror, emitShade, &bc->next_rays, &bc->shades, ib, im, is);
   if (emitBounce) {
     if (ib < rc.capacity) {
       d3 ro = P + wdir * MIPT_RAY_EPSILON;  // RayTracer.cpp:259
@@ -678,9 +703,9 @@ void launch_shade(const SceneDev &S, const RenderConst &rc, RayQueue q, uint32_t
                   RayQueue next, ShadeList sl, BatchCounts *bc, double *accum, DeviceCounters *dc, bool count, hipStream_t st) {
   if (!n) return;
   if (count)
-    hipLaunchKernelGGL(k_shade<true>, dim3(grid_for(n)), dim3(kBlock), 0, st, S, rc, q, n, hit_t, hit_prim, next, sl, bc, accum, dc);
+    hipLaunchKernelGGL(k_shade<true>, dim3((n + kShadeBlock - 1) / kShadeBlock), dim3(kShadeBlock), 0, st, S, rc, q, n, hit_t, hit_prim, next, sl, bc, accum, dc);
   else
-    hipLaunchKernelGGL(k_shade<false>, dim3(grid_for(n)), dim3(kBlock), 0, st, S, rc, q, n, hit_t, hit_prim, next, sl, bc, accum, dc);
+    hipLaunchKernelGGL(k_shade<false>, dim3((n + kShadeBlock - 1) / kShadeBlock), dim3(kShadeBlock), 0, st, S, rc, q, n, hit_t, hit_prim, next, sl, bc, accum, dc);
 }
 
 // Moves `n` ray records between queues (spill to / refill from the overflow stack).
