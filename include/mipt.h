@@ -168,7 +168,7 @@ typedef struct mipt_params {
   int32_t sample_end;
   int32_t batch_samples; /* path samples per wavefront batch (also the most
                             rays one kernel launch takes); 0 = default 2^22,
-                            at most 2^24                                       */
+                            at most 2^28                                       */
 } mipt_params;
 
 /* Work counters (summed over everything rendered since the last reset). */

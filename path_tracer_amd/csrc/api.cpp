@@ -166,6 +166,7 @@ RayQueue carve_queue(void *base, uint32_t cap) {
   q.tx = d + 6ull * cap; q.ty = d + 7ull * cap; q.tz = d + 8ull * cap;
   q.key = reinterpret_cast<uint64_t *>(d + 9ull * cap);
   q.slot = reinterpret_cast<uint32_t *>(d + 10ull * cap);
+  q.depth = reinterpret_cast<uint8_t *>(q.slot + cap);
   return q;
 }
 ShadeList carve_shade(void *base, uint32_t cap) {
@@ -178,7 +179,7 @@ ShadeList carve_shade(void *base, uint32_t cap) {
   s.slot = reinterpret_cast<uint32_t *>(d + 10ull * cap);
   return s;
 }
-constexpr size_t kEntryBytes = 10 * sizeof(double) + sizeof(uint32_t);  // per queue / shade-list entry
+constexpr size_t kEntryBytes = 10 * sizeof(double) + sizeof(uint32_t) + 1;  // per queue / shade-list entry
 
 int check_params(mipt_ctx *c, const mipt_params *p) {
   if (!p) return set_err(c, MIPT_ERR_INVALID, "null params");
@@ -402,7 +403,7 @@ int mipt_render_accumulate(mipt_ctx *c, const mipt_params *p, double *d_sum, voi
   int64_t PB = std::max<int64_t>(1, B / SB);
   PB = std::min<int64_t>(PB, owned);
   int64_t batch = PB * SB;
-  if (batch > (1ll << 24)) return set_err(c, MIPT_ERR_LIMIT, "batch_samples too large (limit 2^24)");
+  if (batch > (1ll << 28)) return set_err(c, MIPT_ERR_LIMIT, "batch_samples too large (limit 2^28)");
   uint32_t cap = (uint32_t)(2 * batch + 1024);
   c->capacity = cap;
   if ((r = ensure(c, c->queue[0], (size_t)cap * kEntryBytes + 64)) != MIPT_OK) return r;

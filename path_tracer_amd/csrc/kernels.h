@@ -16,9 +16,9 @@ struct RayQueue {
   double *dx, *dy, *dz;  // unit direction
   double *tx, *ty, *tz;  // throughput of the edge (what its radiance is multiplied by)
   uint64_t *key;         // random-stream key of the path node this ray arrives at
-  uint32_t *slot;        // depth << 24 | sample accumulator the edge deposits into
+  uint32_t *slot;        // sample accumulator the edge deposits into
+  uint8_t *depth;        // tree level of the edge (camera ray = 0)
 };
-constexpr size_t kRayBytes = 9 * sizeof(double) + sizeof(uint64_t) + sizeof(uint32_t);
 
 // Shaded hits waiting for their shadow rays.
 struct ShadeList {

@@ -161,7 +161,8 @@ __global__ void __launch_bounds__(kBlock) k_generate(SceneDev S, RenderConst rc,
   q.dx[idx] = dir.x; q.dy[idx] = dir.y; q.dz[idx] = dir.z;
   q.tx[idx] = 1.0; q.ty[idx] = 1.0; q.tz[idx] = 1.0;
   q.key[idx] = sample_key(rc.seed, (uint64_t)i + (uint64_t)j * (uint64_t)rc.width, (uint64_t)(sample0 + (int)k));
-  q.slot[idx] = idx;  // depth 0 in the high byte
+  q.slot[idx] = idx;
+  q.depth[idx] = 0;
 }
 
 // --------------------------------------------------------------- intersect ----
@@ -255,9 +256,8 @@ __global__ void __launch_bounds__(kShadeBlock) k_shade(SceneDev S, RenderConst r
     d3 d{q.dx[idx], q.dy[idx], q.dz[idx]};
     d3 T{q.tx[idx], q.ty[idx], q.tz[idx]};
     key = q.key[idx];
-    uint32_t sd = q.slot[idx];  // depth << 24 | sample slot
-    slot = sd & 0x00ffffffu;
-    depth = (int)(sd >> 24);
+    slot = q.slot[idx];
+    depth = (int)q.depth[idx];
     if (prim < 0) {
       // miss branch, RayTracer.cpp:279-304
       if (S.has_cubemap) deposit(accum, slot, T * cube_color(S, d));
@@ -346,7 +346,8 @@ __global__ void __launch_bounds__(kShadeBlock) k_shade(SceneDev S, RenderConst r
       nq.dx[ib] = wdir.x; nq.dy[ib] = wdir.y; nq.dz[ib] = wdir.z;
       nq.tx[ib] = Tb.x; nq.ty[ib] = Tb.y; nq.tz[ib] = Tb.z;
       nq.key[ib] = mix64(key, SLOT_CHILD_BOUNCE);
-      nq.slot[ib] = slot | ((uint32_t)(depth + 1) << 24);
+      nq.slot[ib] = slot;
+      nq.depth[ib] = (uint8_t)(depth + 1);
     } else {
       bc->overflow = 1;
     }
@@ -358,7 +359,8 @@ __global__ void __launch_bounds__(kShadeBlock) k_shade(SceneDev S, RenderConst r
       nq.dx[im] = rdir.x; nq.dy[im] = rdir.y; nq.dz[im] = rdir.z;
       nq.tx[im] = Tm.x; nq.ty[im] = Tm.y; nq.tz[im] = Tm.z;
       nq.key[im] = mix64(key, SLOT_CHILD_MIRROR);
-      nq.slot[im] = slot | ((uint32_t)(depth + 1) << 24);
+      nq.slot[im] = slot;
+      nq.depth[im] = (uint8_t)(depth + 1);
     } else {
       bc->overflow = 1;
     }
@@ -718,6 +720,7 @@ __global__ void __launch_bounds__(kBlock) k_copy_rays(RayQueue src, uint64_t src
   dst.tx[b] = src.tx[a]; dst.ty[b] = src.ty[a]; dst.tz[b] = src.tz[a];
   dst.key[b] = src.key[a];
   dst.slot[b] = src.slot[a];
+  dst.depth[b] = src.depth[a];
 }
 
 void launch_copy_rays(RayQueue src, uint64_t src_off, RayQueue dst, uint64_t dst_off, uint32_t n, hipStream_t st) {
