@@ -192,7 +192,8 @@ typedef struct mipt_counters {
 #define MIPT_K_SHADE 2
 #define MIPT_K_SHADOW 3
 #define MIPT_K_RESOLVE 4
-#define MIPT_K_COUNT 5
+#define MIPT_K_SHADOW_SUM 5 /* per-hit sum of the shadow rays' results */
+#define MIPT_K_COUNT 6
 typedef struct mipt_kernel_times {
   double ms[MIPT_K_COUNT];        /* summed HIP-event durations, milliseconds */
   uint64_t launches[MIPT_K_COUNT];

@@ -13,8 +13,8 @@ LIGHT_DIRECTIONAL, LIGHT_POINT, LIGHT_RECT_AREA = 0, 1, 2
 FLAG_FIXED_AREA_PATTERN = 1
 FLAG_COUNTERS = 2
 FLAG_PROFILE = 4
-K_GENERATE, K_INTERSECT, K_SHADE, K_SHADOW, K_RESOLVE, K_COUNT = 0, 1, 2, 3, 4, 5
-KERNEL_NAMES = ("generate", "intersect", "shade", "shadow", "resolve")
+K_GENERATE, K_INTERSECT, K_SHADE, K_SHADOW, K_RESOLVE, K_SHADOW_SUM, K_COUNT = 0, 1, 2, 3, 4, 5, 6
+KERNEL_NAMES = ("generate", "intersect", "shade", "shadow", "resolve", "shadow_sum")
 
 OK, ERR_INVALID, ERR_NOSCENE, ERR_DEVICE, ERR_NOMEM, ERR_LIMIT = 0, -1, -2, -3, -4, -5
 
@@ -132,10 +132,10 @@ class Counters(C.Structure):
 
 
 class KernelTimes(C.Structure):
-    _fields_ = [("ms", C.c_double * 5), ("launches", C.c_uint64 * 5), ("items", C.c_uint64 * 5)]
+    _fields_ = [("ms", C.c_double * K_COUNT), ("launches", C.c_uint64 * K_COUNT), ("items", C.c_uint64 * K_COUNT)]
 
     def as_dict(self):
-        return {KERNEL_NAMES[k]: {"ms": float(self.ms[k]), "launches": int(self.launches[k]), "items": int(self.items[k])} for k in range(5)}
+        return {KERNEL_NAMES[k]: {"ms": float(self.ms[k]), "launches": int(self.launches[k]), "items": int(self.items[k])} for k in range(K_COUNT)}
 
 
 def default_params(width: int, height: int, **over) -> Params:

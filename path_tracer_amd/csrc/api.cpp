@@ -413,9 +413,10 @@ int mipt_render_accumulate(mipt_ctx *c, const mipt_params *p, double *d_sum, voi
   if ((r = ensure(c, c->accum, (size_t)batch * 3 * sizeof(double))) != MIPT_OK) return r;
   if ((r = ensure(c, c->rows, rows.size() * sizeof(int))) != MIPT_OK) return r;
   if ((r = ensure(c, c->counts, sizeof(BatchCounts))) != MIPT_OK) return r;
-  // visibility scratch: all shadow rays of a level if they fit 2^27 rays, else chunks of whole hits
+  // visibility scratch: all shadow rays of a level if they fit 2^30 rays, else chunks of whole hits
   uint64_t rays_per_hit = (uint64_t)std::max(1, c->dev.rays_per_hit);
-  uint64_t vis_rays = std::max<uint64_t>(std::min<uint64_t>((uint64_t)cap * rays_per_hit, 1ull << 27), rays_per_hit);
+  uint64_t vis_rays = std::max<uint64_t>(std::min<uint64_t>((uint64_t)cap * rays_per_hit, 1ull << 30), rays_per_hit);
+  const uint64_t hits_per_chunk = std::min<uint64_t>(vis_rays / rays_per_hit, 0xffffff00ull / rays_per_hit);
   if ((r = ensure(c, c->vis, vis_rays * sizeof(double) * (c->dev.translucent ? 3 : 1))) != MIPT_OK) return r;
   if (!c->dcount.p) {
     if ((r = ensure(c, c->dcount, sizeof(DeviceCounters))) != MIPT_OK) return r;
@@ -469,9 +470,17 @@ int mipt_render_accumulate(mipt_ctx *c, const mipt_params *p, double *d_sum, voi
           tot.ray_stages += 2ull * n + h.shades;
           tot.shadow_rays += (uint64_t)h.shades * (uint64_t)c->dev.rays_per_hit;
         }
-        if (h.shades) {
-          ProfScope ps(c, prof, MIPT_K_SHADOW, (uint64_t)h.shades * (uint64_t)c->dev.rays_per_hit, st);
-          launch_shadow(c->dev, rc, sl, h.shades, reinterpret_cast<double *>(c->vis.p), vis_rays, accum, dc, count, st);
+        // shadow rays of this level, in chunks of whole hits that fit the visibility buffer
+        for (uint64_t h0 = 0; h0 < h.shades; h0 += hits_per_chunk) {
+          uint32_t nh = (uint32_t)std::min<uint64_t>(hits_per_chunk, h.shades - h0);
+          {
+            ProfScope ps(c, prof, MIPT_K_SHADOW, (uint64_t)nh * rays_per_hit, st);
+            launch_shadow_trace(c->dev, rc, sl, h0, nh, reinterpret_cast<double *>(c->vis.p), dc, count, st);
+          }
+          {
+            ProfScope ps(c, prof, MIPT_K_SHADOW_SUM, nh, st);
+            launch_shadow_sum(c->dev, sl, h0, nh, reinterpret_cast<const double *>(c->vis.p), accum, st);
+          }
         }
         uint32_t m = h.next_rays;
         cur ^= 1;

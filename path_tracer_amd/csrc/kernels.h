@@ -64,8 +64,9 @@ void launch_shade(const SceneDev &S, const RenderConst &rc, RayQueue q, uint32_t
 void launch_copy_rays(RayQueue src, uint64_t src_off, RayQueue dst, uint64_t dst_off, uint32_t n, hipStream_t st);
 // vis: scratch for the per-ray shadow results, room for vis_rays rays (1 double each, 3 in
 // translucent scenes); the hits are processed in chunks that fit it.
-void launch_shadow(const SceneDev &S, const RenderConst &rc, ShadeList sl, uint32_t n_shades, double *vis, uint64_t vis_rays,
-                   double *accum, DeviceCounters *dc, bool count, hipStream_t st);
+void launch_shadow_trace(const SceneDev &S, const RenderConst &rc, ShadeList sl, uint64_t first_hit, uint32_t n_hits, double *vis,
+                         DeviceCounters *dc, bool count, hipStream_t st);
+void launch_shadow_sum(const SceneDev &S, ShadeList sl, uint64_t first_hit, uint32_t n_hits, const double *vis, double *accum, hipStream_t st);
 void launch_resolve(const RenderConst &rc, const double *accum, const int *rows, int64_t first_pixel, int n_pixels,
                     int n_samples, double *d_sum, DeviceCounters *dc, hipStream_t st);
 void launch_finalize(const double *d_sum, int64_t n_pixels, int spp, float *rgb_f32, uint8_t *rgb8, hipStream_t st);

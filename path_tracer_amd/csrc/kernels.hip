@@ -728,26 +728,24 @@ void launch_copy_rays(RayQueue src, uint64_t src_off, RayQueue dst, uint64_t dst
   hipLaunchKernelGGL(k_copy_rays, dim3(grid_for(n)), dim3(kBlock), 0, st, src, src_off, dst, dst_off, n);
 }
 
-void launch_shadow(const SceneDev &S, const RenderConst &rc, ShadeList sl, uint32_t n_shades, double *vis, uint64_t vis_rays, double *accum,
-                   DeviceCounters *dc, bool count, hipStream_t st) {
-  if (!n_shades || !S.rays_per_hit) return;
-  // chunks of whole hits whose rays fit the visibility buffer
+void launch_shadow_trace(const SceneDev &S, const RenderConst &rc, ShadeList sl, uint64_t first_hit, uint32_t n_hits, double *vis,
+                         DeviceCounters *dc, bool count, hipStream_t st) {
   uint64_t R = (uint64_t)S.rays_per_hit;
-  uint64_t hits_per = vis_rays / R;
-  if (hits_per == 0) return;
-  for (uint64_t h0 = 0; h0 < n_shades; h0 += hits_per) {
-    uint32_t nh = (uint32_t)((n_shades - h0 < hits_per) ? n_shades - h0 : hits_per);
-    uint32_t items = (uint32_t)(nh * R);
-    if (S.translucent) {
-      auto kern = count ? k_shadow_walk<true> : k_shadow_walk<false>;
-      hipLaunchKernelGGL(kern, dim3(grid_for(items)), dim3(kBlock), stack_bytes(S), st, S, rc, sl, h0 * R, items, vis, dc);
-      hipLaunchKernelGGL(k_shadow_sum<true>, dim3(grid_for(nh)), dim3(kBlock), 0, st, S, sl, (uint32_t)h0, nh, vis, accum);
-    } else {
-      auto kern = count ? k_shadow_any<true> : k_shadow_any<false>;
-      hipLaunchKernelGGL(kern, dim3(persistent_grid(rc, items)), dim3(kBlock), stack_bytes(S), st, S, rc, sl, h0 * R, items, vis, dc);
-      hipLaunchKernelGGL(k_shadow_sum<false>, dim3(grid_for(nh)), dim3(kBlock), 0, st, S, sl, (uint32_t)h0, nh, vis, accum);
-    }
+  if (!n_hits || !R) return;
+  uint32_t items = (uint32_t)(n_hits * R);
+  if (S.translucent) {
+    auto kern = count ? k_shadow_walk<true> : k_shadow_walk<false>;
+    hipLaunchKernelGGL(kern, dim3(grid_for(items)), dim3(kBlock), stack_bytes(S), st, S, rc, sl, first_hit * R, items, vis, dc);
+  } else {
+    auto kern = count ? k_shadow_any<true> : k_shadow_any<false>;
+    hipLaunchKernelGGL(kern, dim3(persistent_grid(rc, items)), dim3(kBlock), stack_bytes(S), st, S, rc, sl, first_hit * R, items, vis, dc);
   }
+}
+
+void launch_shadow_sum(const SceneDev &S, ShadeList sl, uint64_t first_hit, uint32_t n_hits, const double *vis, double *accum, hipStream_t st) {
+  if (!n_hits || !S.rays_per_hit) return;
+  auto kern = S.translucent ? k_shadow_sum<true> : k_shadow_sum<false>;
+  hipLaunchKernelGGL(kern, dim3(grid_for(n_hits)), dim3(kBlock), 0, st, S, sl, (uint32_t)first_hit, n_hits, vis, accum);
 }
 
 void launch_resolve(const RenderConst &rc, const double *accum, const int *rows, int64_t first_pixel, int n_pixels, int n_samples,

@@ -1,0 +1,68 @@
+// Micro-benchmark of the vector-L1 path for the BVH gather pattern: every lane walks a
+// dependent chain of random 64-byte records, loading NL x 16 bytes of each.
+// Prints cycles per wave-step per CU for several footprints and load widths.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
+
+template <int NL, int ACTIVE>
+__global__ void __launch_bounds__(256, 6) gather(const float4 *__restrict__ nodes, uint32_t mask, int steps, float *out) {
+  uint32_t tid = blockIdx.x * 256 + threadIdx.x;
+  uint32_t idx = tid * 2654435761u + 12345u;
+  float acc = 0.f;
+  if ((threadIdx.x & 63) < ACTIVE) {
+    for (int s = 0; s < steps; s++) {
+      const float4 *p = nodes + (size_t)(idx & mask) * 4;
+      float4 a = p[0];
+      acc += a.x;
+      uint32_t dep = __float_as_uint(a.w);
+      if (NL > 1) { float4 b = p[1]; acc += b.y; dep += __float_as_uint(b.w); }
+      if (NL > 2) { float4 c = p[2]; acc += c.z; dep += __float_as_uint(c.w); }
+      if (NL > 3) { float4 d = p[3]; acc += d.x; dep += __float_as_uint(d.w); }
+      idx = idx * 1664525u + 1013904223u + dep;
+      idx ^= idx >> 15;
+    }
+  }
+  out[tid] = acc + (float)idx;
+}
+
+template <int NL, int ACTIVE>
+static void run(const float4 *d_nodes, uint32_t mask, float *d_out, int cus, double mhz) {
+  const int steps = 2000;
+  int grid = cus * 6;
+  hipEvent_t e0, e1;
+  CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+  hipLaunchKernelGGL((gather<NL, ACTIVE>), dim3(grid), dim3(256), 0, 0, d_nodes, mask, 200, d_out);
+  CHECK(hipEventRecord(e0));
+  hipLaunchKernelGGL((gather<NL, ACTIVE>), dim3(grid), dim3(256), 0, 0, d_nodes, mask, steps, d_out);
+  CHECK(hipEventRecord(e1));
+  CHECK(hipEventSynchronize(e1));
+  float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+  double wave_steps_per_cu = 24.0 * steps;
+  double cyc = ms * 1e-3 * mhz * 1e6 / wave_steps_per_cu;
+  printf("  loads %d x16B  active lanes %2d  footprint %8.1f KiB : %7.3f ms  %6.1f cycles per wave-step per CU  (%.1f per lane-load)\n", NL, ACTIVE,
+         (mask + 1) * 64.0 / 1024, ms, cyc, cyc / (NL * ACTIVE));
+}
+
+int main() {
+  hipDeviceProp_t prop; CHECK(hipGetDeviceProperties(&prop, 0));
+  int cus = prop.multiProcessorCount; double mhz = prop.clockRate / 1000.0;
+  printf("%s, %d CUs, %.0f MHz\n", prop.name, cus, mhz);
+  size_t n = 1u << 22;  // 256 MiB of records
+  std::vector<float4> h(n * 4, float4{1.f, 2.f, 3.f, 0.f});
+  float4 *d; float *out;
+  CHECK(hipMalloc(&d, n * 64)); CHECK(hipMalloc(&out, (size_t)cus * 6 * 256 * 4));
+  CHECK(hipMemcpy(d, h.data(), n * 64, hipMemcpyHostToDevice));
+  for (uint32_t recs : {128u, 4096u, 1u << 16, 1u << 18, 1u << 21}) {
+    uint32_t mask = recs - 1;
+    run<1, 64>(d, mask, out, cus, mhz);
+    run<2, 64>(d, mask, out, cus, mhz);
+    run<4, 64>(d, mask, out, cus, mhz);
+    run<4, 26>(d, mask, out, cus, mhz);
+    run<2, 26>(d, mask, out, cus, mhz);
+  }
+  return 0;
+}
