@@ -245,6 +245,7 @@ def main():
                 "node_visits": cnt["node_visits"] / step_samples,
                 "prim_tests": cnt["prim_tests"] / step_samples,
             },
+            "counters": cnt,
             "mrays_per_s": (cnt["path_rays"] + cnt["shadow_rays"]) / step_samples * samples_total / elapsed / 1e6,
             "scene_upload_s": upload_s,
         }

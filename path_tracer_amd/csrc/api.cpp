@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -41,6 +42,7 @@ struct mipt_ctx {
   uint32_t capacity = 0;
   DevBuf queue[2], shade, hits, accum, rows, counts, dcount;
   DevBuf vis;                // per-shadow-ray results of one chunk of hits
+  int n_cus = 256;
   int persist_blocks = 1536; // CUs x blocks per CU for the persistent traversal kernels
   DevBuf spill;              // overflow stack of ray records (allocated on first use)
   uint64_t spill_cap = 0;    // entries
@@ -293,7 +295,7 @@ int mipt_create(mipt_ctx **out, int device) {
   std::memset(&c->dev, 0, sizeof(c->dev));
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
-    c->persist_blocks = prop.multiProcessorCount * 6;  // the traversal kernels are built for 6 waves per SIMD
+    c->n_cus = prop.multiProcessorCount;
   *out = c;
   return MIPT_OK;
 }
@@ -345,7 +347,26 @@ int mipt_upload_scene(mipt_ctx *c, const mipt_scene_desc *desc) {
   D.n_lights = (int)H.lights.size();
   D.n_materials = (int)H.materials.size();
   D.n_prims = (int)H.prim_info.size();
-  D.stack_entries = H.max_depth + 2;
+  // traversal stacks: up to kLdsStackMax entries per lane in LDS (6 blocks x 256 lanes x 24
+  // entries fill 144 of a CU's 160 KB), the rest of the worst case in global memory
+  const int kLdsStackMax = 24;
+  int lds_entries = kLdsStackMax;
+  if (const char *e = std::getenv("MIPT_LDS_STACK")) {  // test and tuning knob
+    int v = std::atoi(e);
+    if (v >= 1 && v <= 60) lds_entries = v;
+  }
+  D.stack_entries = std::min(H.stack_need, lds_entries);
+  c->persist_blocks = c->n_cus * traversal_blocks_per_cu(D);
+  D.ovf_stride = (uint32_t)c->persist_blocks * 256u;
+  {
+    size_t extra = (size_t)std::max(0, H.stack_need - D.stack_entries);
+    void *p = nullptr;
+    size_t bytes = std::max<size_t>(extra * D.ovf_stride * sizeof(uint32_t), 16);
+    HIP_TRY(c, hipMalloc(&p, bytes));
+    c->scene_allocs.push_back(p);
+    c->scene_bytes += (int64_t)bytes;
+    D.stack_ovf = reinterpret_cast<uint32_t *>(p);
+  }
   D.translucent = H.translucent ? 1 : 0;
   D.radius = H.radius;
   std::memcpy(D.ambient, H.ambient, sizeof(D.ambient));
@@ -360,14 +381,12 @@ int mipt_upload_scene(mipt_ctx *c, const mipt_scene_desc *desc) {
       D.cube_h[f] = H.cube_h[f];
     }
   }
-  if ((size_t)D.stack_entries * 256 * 4 > 64 * 1024)
-    return set_err(c, MIPT_ERR_LIMIT, "BVH too deep for the LDS traversal stack (%d levels)", H.max_depth);
   c->n_prims = (int64_t)H.prim_info.size();
   c->n_nodes = (int64_t)H.nodes.size();
   c->lights_host = H.lights;
   c->lights_area_samples = -1;
   // drop the big host copies
-  std::vector<Node>().swap(H.nodes);
+  std::vector<Node4>().swap(H.nodes);
   std::vector<Tri>().swap(H.tris);
   std::vector<TriNormals>().swap(H.tri_normals);
   std::vector<uint32_t>().swap(H.prim_info);

@@ -6,8 +6,9 @@
 //
 // Result contract: the closest primitive hit with t < t_max, ties in t broken by the
 // reference's visiting order (ref_order) — what the reference's unordered, un-pruned
-// walk with `test.t < i.t` returns.  Box tests are fp32 and conservative (they may
-// only accept too much), so the result does not depend on the tree shape.
+// walk with `test.t < i.t` returns.  Box tests are fp32 on 8-bit quantised boxes and
+// conservative (they may only accept too much), so the result does not depend on the
+// tree shape or on the quantisation.
 #ifndef MIPT_INTERSECT_H_
 #define MIPT_INTERSECT_H_
 
@@ -19,7 +20,7 @@ namespace mipt {
 #define MIPT_RAY_EPSILON 0.00000001  // scene/ray.h:147
 
 struct SceneDev {
-  const Node *nodes;
+  const Node4 *nodes;
   const Tri *tris;
   const TriNormals *tri_normals;  // may be null
   const uint32_t *prim_info;
@@ -31,7 +32,9 @@ struct SceneDev {
   int n_materials;
   int n_prims;
   int rays_per_hit;
-  int stack_entries;  // LDS traversal stack entries per lane
+  int stack_entries;  // LDS traversal stack entries per lane; deeper entries go to stack_ovf
+  uint32_t *stack_ovf;     // overflow of the traversal stacks: entry k of thread g at [k * ovf_stride + g]
+  uint32_t ovf_stride;     // threads the overflow area is laid out for
   int translucent;
   double radius;
   double ambient[3];
@@ -144,9 +147,10 @@ __device__ __forceinline__ bool tri_hit(const Tri *tr, d3 org, d3 dir, double &t
 }
 
 // ---- conservative fp32 slab culling --------------------------------------------
-// t_axis = b * id + off, with off lowered (near planes) or raised (far planes) by
-// pad = 2^-21 * (R + |o|) * |1/d|: more than the error of rounding the origin, the
-// reciprocal and the box to fp32.  Axis-parallel rays use |d| = 1e-30.
+// A plane at coordinate b is crossed at t = b * id + off, with off lowered (near planes)
+// or raised (far planes) by pad = 2^-21 * (R + |o|) * |1/d|: more than the error of
+// rounding the origin and the reciprocal to fp32 and of evaluating b * id in two fmas
+// (trav_round).  Axis-parallel rays use |d| = 1e-30.
 struct Cull {
   float idx, idy, idz;
   float nx, ny, nz;  // near-plane offsets
@@ -171,17 +175,6 @@ __device__ __forceinline__ Cull make_cull(d3 o, d3 d, double R) {
   return c;
 }
 
-// Entry distance of the ray into [mn, mx] (>= 0), or a value > tlimit on a miss.
-__device__ __forceinline__ float slab(const Cull &c, const float *mn, const float *mx, float tlimit) {
-  float ax = c.idx < 0.0f ? mx[0] : mn[0], bx = c.idx < 0.0f ? mn[0] : mx[0];
-  float ay = c.idy < 0.0f ? mx[1] : mn[1], by = c.idy < 0.0f ? mn[1] : mx[1];
-  float az = c.idz < 0.0f ? mx[2] : mn[2], bz = c.idz < 0.0f ? mn[2] : mx[2];
-  float tn = fmaxf(fmaxf(__fmaf_rn(ax, c.idx, c.nx), __fmaf_rn(ay, c.idy, c.ny)), fmaxf(__fmaf_rn(az, c.idz, c.nz), 0.0f));
-  float tf = fminf(fminf(__fmaf_rn(bx, c.idx, c.fx), __fmaf_rn(by, c.idy, c.fy)), fminf(__fmaf_rn(bz, c.idz, c.fz), tlimit));
-  // one rounding of each fma is left: a relative 2^-22 slack covers it
-  return (tn <= tf * 1.0000005f) ? tn : 3.0e38f;
-}
-
 struct Hit {
   double t;
   int prim;  // storage index, -1 = miss
@@ -195,7 +188,7 @@ struct TravCounters {
 // ---- traversal -------------------------------------------------------------------
 // State of one ray's walk through the BVH.  `cur` is the node to visit next: >= 0 an
 // inner node, < 0 a leaf (~cur = first << 3 | count - 1), MIPT_TRAV_DONE when the walk
-// is over.  The stack lives in LDS, one 4-byte column per lane (`stack[k * stride]`).
+// is over.
 #define MIPT_TRAV_DONE ((int)0x80000000)  // ~code of no valid leaf (needs < 2^28 - 1 primitives)
 struct Trav {
   d3 org, dir;
@@ -204,6 +197,25 @@ struct Trav {
   int cur, sp;
   Hit best;
 };
+
+// Traversal stack of one lane: the first S.stack_entries entries live in LDS, one 4-byte
+// column per lane (`lds[k * stride]`); a walk that needs more spills the rest to a
+// column in global memory.  `gtid` numbers the threads of the launch (< S.ovf_stride).
+struct Stack {
+  uint32_t *lds;
+  int stride;
+  uint32_t gtid;
+};
+__device__ __forceinline__ void stack_push(const SceneDev &S, const Stack &st, int &sp, uint32_t v) {
+  if (sp < S.stack_entries) st.lds[sp * st.stride] = v;
+  else S.stack_ovf[(size_t)(sp - S.stack_entries) * S.ovf_stride + st.gtid] = v;
+  sp++;
+}
+__device__ __forceinline__ uint32_t stack_pop(const SceneDev &S, const Stack &st, int &sp) {
+  sp--;
+  if (sp < S.stack_entries) return st.lds[sp * st.stride];
+  return S.stack_ovf[(size_t)(sp - S.stack_entries) * S.ovf_stride + st.gtid];
+}
 
 __device__ __forceinline__ void trav_init(Trav &T, const SceneDev &S, d3 org, d3 dir, double tmax) {
   T.org = org;
@@ -216,41 +228,73 @@ __device__ __forceinline__ void trav_init(Trav &T, const SceneDev &S, d3 org, d3
   T.best.prim = -1;
 }
 
+__device__ __forceinline__ float ubyte_f(uint32_t w, int k) { return (float)((w >> (8 * k)) & 0xffu); }  // v_cvt_f32_ubyteK
+
+#define MIPT_CSWAP(a, b)                                        \
+  if (t[b] < t[a]) {                                            \
+    float tt_ = t[a]; t[a] = t[b]; t[b] = tt_;                  \
+    int cc_ = ch[a]; ch[a] = ch[b]; ch[b] = cc_;                \
+  }
+
 // One round of the "while-while" walk: descend through inner nodes until the lane holds a
 // leaf (or is done), then test that leaf's primitives and pop the next node.  Keeping the
 // two phases apart lets the lanes of a wave run the fp64 primitive tests together instead
 // of paying for both bodies on every iteration.
-// Closest hit (ANY = false): keeps the smallest (t, ref_order).  Any hit (ANY = true): the
-// first primitive found with t < tmax ends the walk.
+//
+// Inner node: the ray is moved into the node's quantised frame once (per axis
+// t = q * (step / d) + ((origin - o) / d -+ pad)), then each child costs six byte->float
+// conversions and six fmas.  The error of the extra fma stays inside the pad of make_cull
+// (about 2 of its 8 units of 2^-24 (R + |o|) |1/d| are used).
+// Closest hit (ANY = false): children are entered near to far, and the smallest
+// (t, ref_order) is kept.  Any hit (ANY = true): children are entered in slot order (the
+// builder puts large boxes first) and the first primitive with t < tmax ends the walk.
 template <bool ANY, bool COUNT>
-__device__ __forceinline__ void trav_round(Trav &T, const SceneDev &S, uint32_t *stack, int stride, TravCounters &tc) {
+__device__ __forceinline__ void trav_round(Trav &T, const SceneDev &S, const Stack &stk, TravCounters &tc) {
   int cur = T.cur, sp = T.sp;
   while (cur >= 0) {
-    const float4 *np = reinterpret_cast<const float4 *>(S.nodes + cur);
-    float4 q0 = np[0], q1 = np[1], q2 = np[2];
+    const uint4 *np = reinterpret_cast<const uint4 *>(S.nodes + cur);
+    uint4 q0 = np[0], q1 = np[1], q2 = np[2];
     int4 q3 = *reinterpret_cast<const int4 *>(np + 3);
     if (COUNT) tc.nodes++;
-    float lmin[3] = {q0.x, q0.y, q0.z}, lmax[3] = {q0.w, q1.x, q1.y};
-    float rmin[3] = {q1.z, q1.w, q2.x}, rmax[3] = {q2.y, q2.z, q2.w};
-    float tl = slab(T.c, lmin, lmax, T.tlimit);
-    float tr = slab(T.c, rmin, rmax, T.tlimit);
-    bool hl = tl < 2.0e38f, hr = tr < 2.0e38f;
-    if (hl && hr) {
-      int nearc = q3.x, farc = q3.y;
-      if (tr < tl) { nearc = q3.y; farc = q3.x; }
-      stack[sp * stride] = (uint32_t)farc;
-      sp++;
-      cur = nearc;
-    } else if (hl) {
-      cur = q3.x;
-    } else if (hr) {
-      cur = q3.y;
-    } else if (sp == 0) {
-      cur = MIPT_TRAV_DONE;
-    } else {
-      sp--;
-      cur = (int)stack[sp * stride];
+    const float ax = __uint_as_float((q0.w & 0xffu) << 23) * T.c.idx;
+    const float ay = __uint_as_float(((q0.w >> 8) & 0xffu) << 23) * T.c.idy;
+    const float az = __uint_as_float(((q0.w >> 16) & 0xffu) << 23) * T.c.idz;
+    const float ox = __uint_as_float(q0.x), oy = __uint_as_float(q0.y), oz = __uint_as_float(q0.z);
+    const float bnx = __fmaf_rn(ox, T.c.idx, T.c.nx), bfx = __fmaf_rn(ox, T.c.idx, T.c.fx);
+    const float bny = __fmaf_rn(oy, T.c.idy, T.c.ny), bfy = __fmaf_rn(oy, T.c.idy, T.c.fy);
+    const float bnz = __fmaf_rn(oz, T.c.idz, T.c.nz), bfz = __fmaf_rn(oz, T.c.idz, T.c.fz);
+    // the plane a ray enters through is the upper one on axes it travels down
+    const uint32_t nX = T.c.idx < 0.0f ? q1.w : q1.x, fX = T.c.idx < 0.0f ? q1.x : q1.w;
+    const uint32_t nY = T.c.idy < 0.0f ? q2.x : q1.y, fY = T.c.idy < 0.0f ? q1.y : q2.x;
+    const uint32_t nZ = T.c.idz < 0.0f ? q2.y : q1.z, fZ = T.c.idz < 0.0f ? q1.z : q2.y;
+    int ch[4] = {q3.x, q3.y, q3.z, q3.w};
+    float t[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      float tn = fmaxf(fmaxf(__fmaf_rn(ubyte_f(nX, k), ax, bnx), __fmaf_rn(ubyte_f(nY, k), ay, bny)),
+                       fmaxf(__fmaf_rn(ubyte_f(nZ, k), az, bnz), 0.0f));
+      float tf = fminf(fminf(__fmaf_rn(ubyte_f(fX, k), ax, bfx), __fmaf_rn(ubyte_f(fY, k), ay, bfy)),
+                       fminf(__fmaf_rn(ubyte_f(fZ, k), az, bfz), T.tlimit));
+      // one rounding of the last fma is left on each side: a relative 2^-22 slack covers it
+      t[k] = (tn <= tf * 1.0000005f && ch[k] != kNoChild) ? tn : 3.0e38f;
     }
+    if (!ANY) {
+      MIPT_CSWAP(0, 1) MIPT_CSWAP(2, 3) MIPT_CSWAP(0, 2) MIPT_CSWAP(1, 3) MIPT_CSWAP(1, 2)
+    }
+    // enter the first child that was hit, stack the others (last first)
+    int nxt = MIPT_TRAV_DONE;
+    bool have = false;
+#pragma unroll
+    for (int k = 3; k >= 0; k--) {
+      if (t[k] < 2.0e38f) {
+        if (have) stack_push(S, stk, sp, (uint32_t)nxt);
+        nxt = ch[k];
+        have = true;
+      }
+    }
+    if (have) cur = nxt;
+    else if (sp == 0) cur = MIPT_TRAV_DONE;
+    else cur = (int)stack_pop(S, stk, sp);
   }
   if (cur != MIPT_TRAV_DONE) {
     uint32_t code = (uint32_t)~cur;
@@ -281,12 +325,8 @@ __device__ __forceinline__ void trav_round(Trav &T, const SceneDev &S, uint32_t 
         }
       }
     }
-    if (found || sp == 0) {
-      cur = MIPT_TRAV_DONE;
-    } else {
-      sp--;
-      cur = (int)stack[sp * stride];
-    }
+    if (found || sp == 0) cur = MIPT_TRAV_DONE;
+    else cur = (int)stack_pop(S, stk, sp);
   }
   T.cur = cur;
   T.sp = sp;
@@ -294,10 +334,10 @@ __device__ __forceinline__ void trav_round(Trav &T, const SceneDev &S, uint32_t 
 
 // The whole walk of one ray.
 template <bool ANY, bool COUNT>
-__device__ __forceinline__ Hit traverse(const SceneDev &S, d3 org, d3 dir, double tmax, uint32_t *stack, int stride, TravCounters &tc) {
+__device__ __forceinline__ Hit traverse(const SceneDev &S, d3 org, d3 dir, double tmax, const Stack &stk, TravCounters &tc) {
   Trav T;
   trav_init(T, S, org, dir, tmax);
-  while (T.cur != MIPT_TRAV_DONE) trav_round<ANY, COUNT>(T, S, stack, stride, tc);
+  while (T.cur != MIPT_TRAV_DONE) trav_round<ANY, COUNT>(T, S, stk, tc);
   return T.best;
 }
 

@@ -64,6 +64,7 @@ void launch_shade(const SceneDev &S, const RenderConst &rc, RayQueue q, uint32_t
 void launch_copy_rays(RayQueue src, uint64_t src_off, RayQueue dst, uint64_t dst_off, uint32_t n, hipStream_t st);
 // vis: scratch for the per-ray shadow results, room for vis_rays rays (1 double each, 3 in
 // translucent scenes); the hits are processed in chunks that fit it.
+int traversal_blocks_per_cu(const SceneDev &S);
 void launch_shadow_trace(const SceneDev &S, const RenderConst &rc, ShadeList sl, uint64_t first_hit, uint32_t n_hits, double *vis,
                          DeviceCounters *dc, bool count, hipStream_t st);
 void launch_shadow_sum(const SceneDev &S, ShadeList sl, uint64_t first_hit, uint32_t n_hits, const double *vis, double *accum, hipStream_t st);

@@ -188,7 +188,7 @@ template <bool COUNT>
 __global__ void __launch_bounds__(kBlock, MIPT_TRAV_WAVES) k_intersect(SceneDev S, RenderConst rc, RayQueue q, uint32_t n, double *__restrict__ hit_t,
                                                                         int *__restrict__ hit_prim, DeviceCounters *dc) {
   extern __shared__ uint32_t lds_stack[];
-  uint32_t *stack = lds_stack + threadIdx.x;
+  const Stack stack{lds_stack + threadIdx.x, kBlock, blockIdx.x * kBlock + threadIdx.x};
   const uint32_t lane = lane_id();
   const uint32_t wave = blockIdx.x * (kBlock / 64) + threadIdx.x / 64;
   const uint32_t n_waves = gridDim.x * (kBlock / 64);
@@ -219,7 +219,7 @@ __global__ void __launch_bounds__(kBlock, MIPT_TRAV_WAVES) k_intersect(SceneDev 
     if (__ballot(!idle) == 0ull) break;
     const uint32_t want_idle = exhausted ? 64u : kRefillIdle;
     do {
-      trav_round<false, COUNT>(T, S, stack, kBlock, tc);
+      trav_round<false, COUNT>(T, S, stack, tc);
       if (!idle && T.cur == MIPT_TRAV_DONE) {
         hit_t[ray] = T.best.t;
         hit_prim[ray] = T.best.prim;
@@ -383,16 +383,16 @@ __global__ void __launch_bounds__(kShadeBlock) k_shade(SceneDev S, RenderConst r
 // The occluder walk of light.cpp:21-33 / 70-83 / 125-138 for translucent scenes.
 template <bool COUNT>
 __device__ d3 shadow_walk(const SceneDev &S, d3 light, d3 p, d3 d, bool has_target, d3 target, double lightT, double tmax,
-                          uint32_t *stack, int stride, TravCounters &tc) {
+                          const Stack &stack, TravCounters &tc) {
   int mat = -1;
-  Hit h = traverse<false, COUNT>(S, p, d, tmax, stack, stride, tc);
+  Hit h = traverse<false, COUNT>(S, p, d, tmax, stack, tc);
   double pt = h.t;
   if (h.prim >= 0) mat = S.objects[S.prim_info[h.prim] & 0x3fffffffu].material;
   int guard = 0;
   while (pt < lightT && guard++ < 4096) {
     d3 entry = p + pt * d;
     p = p + (pt + MIPT_RAY_EPSILON) * d;
-    h = traverse<false, COUNT>(S, p, d, tmax, stack, stride, tc);
+    h = traverse<false, COUNT>(S, p, d, tmax, stack, tc);
     pt = h.t;
     if (h.prim >= 0) mat = S.objects[S.prim_info[h.prim] & 0x3fffffffu].material;
     d3 exitp = p + pt * d;
@@ -400,7 +400,7 @@ __device__ d3 shadow_walk(const SceneDev &S, d3 light, d3 p, d3 d, bool has_targ
     d3 kt = mat >= 0 ? ld3(S.materials[mat].kt) : d3{0, 0, 0};
     light = light * d3{pow(kt.x, dist), pow(kt.y, dist), pow(kt.z, dist)};
     p = p + (pt + MIPT_RAY_EPSILON) * d;
-    h = traverse<false, COUNT>(S, p, d, tmax, stack, stride, tc);
+    h = traverse<false, COUNT>(S, p, d, tmax, stack, tc);
     pt = h.t;
     if (h.prim >= 0) mat = S.objects[S.prim_info[h.prim] & 0x3fffffffu].material;
     if (has_target) lightT = sqrt(dot(target - p, target - p));
@@ -455,16 +455,16 @@ __device__ __forceinline__ ShadowSetup shadow_setup(const RenderConst &rc, const
 // per-ray value, area 1/S excluded.
 template <bool COUNT, bool WALK>
 __device__ d3 shadow_ray(const SceneDev &S, const RenderConst &rc, const LightRec &L, int li, int s, d3 fire, uint64_t key,
-                         uint32_t *stack, int stride, TravCounters &tc) {
+                         const Stack &stack, TravCounters &tc) {
   ShadowSetup su = shadow_setup(rc, L, li, s, fire, key);
   d3 color = ld3(L.color);
   d3 light;
   if (WALK) {
-    light = shadow_walk<COUNT>(S, color, fire, su.dir, su.has_target, su.target, su.lightT, rc.t_max, stack, stride, tc);
+    light = shadow_walk<COUNT>(S, color, fire, su.dir, su.has_target, su.target, su.lightT, rc.t_max, stack, tc);
   } else {
     // every kt is 0: the walk multiplies by pow(0, dist > 0) = 0 on the first occluder,
     // so "any hit closer than the light" decides it
-    Hit h = traverse<true, COUNT>(S, fire, su.dir, fmin(su.lightT, rc.t_max), stack, stride, tc);
+    Hit h = traverse<true, COUNT>(S, fire, su.dir, fmin(su.lightT, rc.t_max), stack, tc);
     light = h.prim >= 0 ? d3{0, 0, 0} : color;
   }
   return light * su.scale;
@@ -486,7 +486,7 @@ template <bool COUNT>
 __global__ void __launch_bounds__(kBlock, MIPT_TRAV_WAVES) k_shadow_any(SceneDev S, RenderConst rc, ShadeList sl, uint64_t first_item, uint32_t n_items,
                                                                          double *__restrict__ vis, DeviceCounters *dc) {
   extern __shared__ uint32_t lds_stack[];
-  uint32_t *stack = lds_stack + threadIdx.x;
+  const Stack stack{lds_stack + threadIdx.x, kBlock, blockIdx.x * kBlock + threadIdx.x};
   const uint32_t lane = lane_id();
   const uint32_t wave = blockIdx.x * (kBlock / 64) + threadIdx.x / 64;
   const uint32_t n_waves = gridDim.x * (kBlock / 64);
@@ -527,7 +527,7 @@ __global__ void __launch_bounds__(kBlock, MIPT_TRAV_WAVES) k_shadow_any(SceneDev
     if (__ballot(!idle) == 0ull) break;
     const uint32_t want_idle = exhausted ? 64u : kRefillIdle;
     do {
-      trav_round<true, COUNT>(T, S, stack, kBlock, tc);
+      trav_round<true, COUNT>(T, S, stack, tc);
       if (!idle && T.cur == MIPT_TRAV_DONE) {
         vis[item] = T.best.prim >= 0 ? 0.0 : scale;
         idle = true;
@@ -546,10 +546,10 @@ template <bool COUNT>
 __global__ void __launch_bounds__(kBlock, 2) k_shadow_walk(SceneDev S, RenderConst rc, ShadeList sl, uint64_t first_item, uint32_t n_items,
                                                             double *__restrict__ vis3, DeviceCounters *dc) {
   extern __shared__ uint32_t lds_stack[];
-  uint32_t it = blockIdx.x * kBlock + threadIdx.x;
+  const Stack stack{lds_stack + threadIdx.x, kBlock, blockIdx.x * kBlock + threadIdx.x};
   TravCounters tc{0, 0};
-  if (it < n_items) {
-    const uint32_t R = (uint32_t)S.rays_per_hit;
+  const uint32_t R = (uint32_t)S.rays_per_hit;
+  for (uint64_t it = stack.gtid; it < n_items; it += (uint64_t)gridDim.x * kBlock) {
     uint64_t w = first_item + it;
     uint32_t h = (uint32_t)(w / R);
     uint32_t r = (uint32_t)(w - (uint64_t)h * R);
@@ -558,7 +558,7 @@ __global__ void __launch_bounds__(kBlock, 2) k_shadow_walk(SceneDev S, RenderCon
     d3 P{sl.px[h], sl.py[h], sl.pz[h]};
     d3 N{sl.nx[h], sl.ny[h], sl.nz[h]};
     d3 fire = P + (N * MIPT_RAY_EPSILON) * 3.0;
-    d3 light = shadow_ray<COUNT, true>(S, rc, L, li, (int)r - L.first_ray, fire, sl.key[h], lds_stack + threadIdx.x, kBlock, tc);
+    d3 light = shadow_ray<COUNT, true>(S, rc, L, li, (int)r - L.first_ray, fire, sl.key[h], stack, tc);
     vis3[3ull * it + 0] = light.x;
     vis3[3ull * it + 1] = light.y;
     vis3[3ull * it + 2] = light.z;
@@ -641,41 +641,57 @@ __global__ void __launch_bounds__(kBlock) k_finalize(const double *__restrict__ 
 __global__ void __launch_bounds__(kBlock) k_intersect_rays(SceneDev S, int64_t n, const double *__restrict__ org, const double *__restrict__ dir,
                                                             double t_max, double *t, int *prim, double *normal) {
   extern __shared__ uint32_t lds_stack[];
-  int64_t idx = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (idx >= n) return;
+  const Stack stack{lds_stack + threadIdx.x, kBlock, blockIdx.x * kBlock + threadIdx.x};
   TravCounters tc{0, 0};
-  d3 o{org[3 * idx], org[3 * idx + 1], org[3 * idx + 2]};
-  d3 d{dir[3 * idx], dir[3 * idx + 1], dir[3 * idx + 2]};
-  Hit h = traverse<false, false>(S, o, d, t_max, lds_stack + threadIdx.x, kBlock, tc);
-  t[idx] = h.t;
-  prim[idx] = h.prim >= 0 ? (int)S.ref_order[h.prim] : -1;
-  d3 N{0, 0, 0};
-  if (h.prim >= 0) N = hit_normal(S, h.prim, o, d);
-  normal[3 * idx] = N.x;
-  normal[3 * idx + 1] = N.y;
-  normal[3 * idx + 2] = N.z;
+  for (int64_t idx = stack.gtid; idx < n; idx += (int64_t)gridDim.x * kBlock) {
+    d3 o{org[3 * idx], org[3 * idx + 1], org[3 * idx + 2]};
+    d3 d{dir[3 * idx], dir[3 * idx + 1], dir[3 * idx + 2]};
+    Hit h = traverse<false, false>(S, o, d, t_max, stack, tc);
+    t[idx] = h.t;
+    prim[idx] = h.prim >= 0 ? (int)S.ref_order[h.prim] : -1;
+    d3 N{0, 0, 0};
+    if (h.prim >= 0) N = hit_normal(S, h.prim, o, d);
+    normal[3 * idx] = N.x;
+    normal[3 * idx + 1] = N.y;
+    normal[3 * idx + 2] = N.z;
+  }
 }
 
 template <bool WALK>
 __global__ void __launch_bounds__(kBlock) k_shadow_attenuation(SceneDev S, RenderConst rc, int li, int64_t n, const double *__restrict__ fire,
                                                                 const uint64_t *__restrict__ key, double *out) {
   extern __shared__ uint32_t lds_stack[];
-  int64_t idx = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (idx >= n) return;
+  const Stack stack{lds_stack + threadIdx.x, kBlock, blockIdx.x * kBlock + threadIdx.x};
   TravCounters tc{0, 0};
   const LightRec &L = S.lights[li];
-  d3 f{fire[3 * idx], fire[3 * idx + 1], fire[3 * idx + 2]};
-  d3 sum{0, 0, 0};
-  for (int s = 0; s < L.samples; s++) sum = sum + shadow_ray<false, WALK>(S, rc, L, li, s, f, key[idx], lds_stack + threadIdx.x, kBlock, tc);
-  if (L.type == MIPT_LIGHT_RECT_AREA) sum = sum / (double)L.samples;
-  out[3 * idx] = sum.x;
-  out[3 * idx + 1] = sum.y;
-  out[3 * idx + 2] = sum.z;
+  for (int64_t idx = stack.gtid; idx < n; idx += (int64_t)gridDim.x * kBlock) {
+    d3 f{fire[3 * idx], fire[3 * idx + 1], fire[3 * idx + 2]};
+    d3 sum{0, 0, 0};
+    for (int s = 0; s < L.samples; s++) sum = sum + shadow_ray<false, WALK>(S, rc, L, li, s, f, key[idx], stack, tc);
+    if (L.type == MIPT_LIGHT_RECT_AREA) sum = sum / (double)L.samples;
+    out[3 * idx] = sum.x;
+    out[3 * idx + 1] = sum.y;
+    out[3 * idx + 2] = sum.z;
+  }
 }
 
 // ---------------------------------------------------------------- launchers ----
 static inline unsigned grid_for(uint64_t n) { return (unsigned)((n + kBlock - 1) / kBlock); }
 static inline size_t stack_bytes(const SceneDev &S) { return (size_t)S.stack_entries * kBlock * sizeof(uint32_t); }
+// Blocks of a traversal kernel one CU holds: the occupancy the kernels are compiled for,
+// or what fits its 160 KB of LDS when the stacks need more.
+int traversal_blocks_per_cu(const SceneDev &S) {
+  size_t per_block = stack_bytes(S) + 256;  // + the kernels' small static LDS
+  int by_lds = (int)((160u * 1024u) / per_block);
+  int n = MIPT_TRAV_WAVES < by_lds ? MIPT_TRAV_WAVES : by_lds;
+  return n < 1 ? 1 : n;
+}
+
+// Grid of a grid-stride traversal kernel: never more threads than the stack overflow area holds.
+static inline unsigned bounded_grid(const SceneDev &S, uint64_t n) {
+  uint64_t full = (n + kBlock - 1) / kBlock, cap = S.ovf_stride / kBlock;
+  return (unsigned)(full < cap ? full : cap);
+}
 
 void launch_generate(const SceneDev &S, const RenderConst &rc, const int *rows, int64_t first_pixel, int n_pixels, int sample0,
                      int n_samples, RayQueue q, hipStream_t st) {
@@ -735,7 +751,7 @@ void launch_shadow_trace(const SceneDev &S, const RenderConst &rc, ShadeList sl,
   uint32_t items = (uint32_t)(n_hits * R);
   if (S.translucent) {
     auto kern = count ? k_shadow_walk<true> : k_shadow_walk<false>;
-    hipLaunchKernelGGL(kern, dim3(grid_for(items)), dim3(kBlock), stack_bytes(S), st, S, rc, sl, first_hit * R, items, vis, dc);
+    hipLaunchKernelGGL(kern, dim3(persistent_grid(rc, items)), dim3(kBlock), stack_bytes(S), st, S, rc, sl, first_hit * R, items, vis, dc);
   } else {
     auto kern = count ? k_shadow_any<true> : k_shadow_any<false>;
     hipLaunchKernelGGL(kern, dim3(persistent_grid(rc, items)), dim3(kBlock), stack_bytes(S), st, S, rc, sl, first_hit * R, items, vis, dc);
@@ -763,14 +779,14 @@ void launch_finalize(const double *d_sum, int64_t n_pixels, int spp, float *rgb_
 void launch_intersect_rays(const SceneDev &S, int64_t n, const double *org, const double *dir, double t_max, double *t, int *prim,
                            double *normal, hipStream_t st) {
   if (!n) return;
-  hipLaunchKernelGGL(k_intersect_rays, dim3(grid_for((uint64_t)n)), dim3(kBlock), stack_bytes(S), st, S, n, org, dir, t_max, t, prim, normal);
+  hipLaunchKernelGGL(k_intersect_rays, dim3(bounded_grid(S, (uint64_t)n)), dim3(kBlock), stack_bytes(S), st, S, n, org, dir, t_max, t, prim, normal);
 }
 
 void launch_shadow_attenuation(const SceneDev &S, const RenderConst &rc, int light, int64_t n, const double *fire, const uint64_t *key,
                                double *out, hipStream_t st) {
   if (!n) return;
   auto kern = S.translucent ? k_shadow_attenuation<true> : k_shadow_attenuation<false>;
-  hipLaunchKernelGGL(kern, dim3(grid_for((uint64_t)n)), dim3(kBlock), stack_bytes(S), st, S, rc, light, n, fire, key, out);
+  hipLaunchKernelGGL(kern, dim3(bounded_grid(S, (uint64_t)n)), dim3(kBlock), stack_bytes(S), st, S, rc, light, n, fire, key, out);
 }
 
 }  // namespace mipt

@@ -10,20 +10,28 @@ namespace mipt {
 // Primitive kinds (top two bits of PrimInfo).
 enum : uint32_t { KIND_SPHERE = 0, KIND_BOX = 1, KIND_SQUARE = 2, KIND_TRI = 3 };
 
-// One BVH2 node, 64 bytes, fetched as four 16-byte loads.  Child boxes are fp32
-// and rounded outward from the fp64 primitive boxes; they only cull, every
-// accepted primitive is tested in fp64.
-//   child >= 0 : index of an inner node
-//   child <  0 : leaf, ~child = (first << 3) | (count - 1), count in 1..8,
-//                `first` indexes the primitive arrays (stored in leaf order)
-//   an absent child has an inverted box (min > max) and is never entered
-struct alignas(16) Node {
-  float lmin[3], lmax[3];
-  float rmin[3], rmax[3];
-  int32_t left, right;
-  int32_t pad0, pad1;
+// One BVH4 node, 64 bytes, fetched as four 16-byte loads.  The boxes of up to four
+// children are 8-bit plane offsets in a frame of the node's own: on axis a child k spans
+//   [origin[a] + lo_k * step_a, origin[a] + hi_k * step_a],   step_a = 2^(exp[a] - 127),
+// with lo_k / hi_k the k-th bytes of lo[a] / hi[a].  The builder rounds the origin and
+// every lower plane down and every upper plane up, so a quantised box contains the
+// fp64 box of its subtree: the boxes only cull, every accepted primitive is tested in
+// fp64, and a coarser box costs time, never a hit.
+//   child >= 0          : index of an inner node
+//   child <  0          : leaf, ~child = (first << 3) | (count - 1), count in 1..8,
+//                         `first` indexes the primitive arrays (stored in leaf order)
+//   child == kNoChild   : absent (children are packed to the front)
+constexpr int32_t kNoChild = (int32_t)0x80000000;
+struct alignas(16) Node4 {
+  float origin[3];
+  uint8_t exp[3];
+  uint8_t n_children;
+  uint32_t lo[3];
+  uint32_t hi[3];
+  uint32_t pad[2];
+  int32_t child[4];
 };
-static_assert(sizeof(Node) == 64, "Node must be 64 bytes");
+static_assert(sizeof(Node4) == 64, "Node4 must be 64 bytes");
 
 // One triangle in world space, 96 bytes (six 16-byte loads):
 //   a  : first vertex

@@ -12,6 +12,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <future>
 #include <limits>
@@ -118,11 +119,6 @@ inline float round_down(double v) {
   if ((double)f > v) f = std::nextafterf(f, -std::numeric_limits<float>::infinity());
   return f;
 }
-inline float round_up(double v) {
-  float f = (float)v;
-  if ((double)f < v) f = std::nextafterf(f, std::numeric_limits<float>::infinity());
-  return f;
-}
 
 // ------------------------------------------------------------- SAH builder ----
 struct BuildPrim {
@@ -131,14 +127,21 @@ struct BuildPrim {
   uint32_t id;  // reference-order index
 };
 
-constexpr int kLeafMax = 4;    // preferred leaf size
+constexpr int kLeafMax = 2;    // preferred leaf size (wide quantised nodes make small leaves pay)
 constexpr int kLeafHard = 8;   // encoding limit (3 bits)
 constexpr int kBins = 16;
 
+// Binary node of the SAH build, before the collapse to four-wide nodes.
+struct BinNode {
+  Box6 box[2];
+  int32_t child[2];
+};
+
 struct Builder {
   std::vector<BuildPrim> &prims;
-  std::vector<Node> nodes;
+  std::vector<BinNode> nodes;
   int max_depth = 0;
+  int leaf_max = kLeafMax;
   explicit Builder(std::vector<BuildPrim> &p) : prims(p) {}
 
   static int32_t leaf_code(size_t first, size_t count) { return ~(int32_t)((first << 3) | (count - 1)); }
@@ -154,7 +157,7 @@ struct Builder {
       cb.grow(D3{prims[i].c[0], prims[i].c[1], prims[i].c[2]});
     }
     *bounds = bb;
-    if (n <= (size_t)kLeafMax) return leaf_code(b, n);
+    if (n <= (size_t)leaf_max) return leaf_code(b, n);
 
     // binned SAH over the three axes
     double bestCost = std::numeric_limits<double>::infinity();
@@ -219,14 +222,107 @@ struct Builder {
     Box6 lb, rb;
     int32_t l = build(b, mid, depth + 1, &lb);
     int32_t r = build(mid, e, depth + 1, &rb);
-    Node &nd = nodes[(size_t)me];
-    for (int a = 0; a < 3; a++) {
-      nd.lmin[a] = round_down(lb.mn[a]); nd.lmax[a] = round_up(lb.mx[a]);
-      nd.rmin[a] = round_down(rb.mn[a]); nd.rmax[a] = round_up(rb.mx[a]);
+    BinNode &nd = nodes[(size_t)me];
+    nd.box[0] = lb;
+    nd.box[1] = rb;
+    nd.child[0] = l;
+    nd.child[1] = r;
+    return me;
+  }
+};
+
+// ---------------------------------------------------- collapse to BVH4 ----
+// Quantises up to four fp64 child boxes into the frame of one Node4 (see layout.h).
+void quantise(Node4 &nd, const Box6 *boxes, const int32_t *refs, int n) {
+  std::memset(&nd, 0, sizeof(nd));
+  nd.n_children = (uint8_t)n;
+  for (int k = 0; k < 4; k++) nd.child[k] = k < n ? refs[k] : kNoChild;
+  for (int a = 0; a < 3; a++) {
+    double lo = std::numeric_limits<double>::infinity(), hi = -lo;
+    for (int k = 0; k < n; k++) {
+      lo = std::min(lo, boxes[k].mn[a]);
+      hi = std::max(hi, boxes[k].mx[a]);
     }
-    nd.left = l;
-    nd.right = r;
-    nd.pad0 = nd.pad1 = 0;
+    if (!(hi >= lo)) { lo = 0; hi = 0; }  // only empty boxes (an empty mesh)
+    float O = round_down(lo);
+    double extent = hi - (double)O;
+    int e = 127 - 60;
+    if (extent > 0) {
+      int ex;
+      std::frexp(extent / 255.0, &ex);  // extent/255 = m * 2^ex, m in [0.5, 1)
+      e = std::max(e, 127 + ex);
+    }
+    for (;; e++) {
+      double step = std::ldexp(1.0, e - 127);
+      bool fits = true;
+      uint32_t lo_w = 0, hi_w = 0;
+      for (int k = 0; k < n && fits; k++) {
+        double mn = boxes[k].mn[a], mx = boxes[k].mx[a];
+        if (!(mx >= mn)) { mn = lo; mx = lo; }
+        double ql = std::floor((mn - (double)O) / step);
+        double qh = std::ceil((mx - (double)O) / step);
+        if ((double)O + ql * step > mn) ql -= 1;
+        if ((double)O + qh * step < mx) qh += 1;
+        if (ql < 0) ql = 0;
+        if (qh > 255) { fits = false; break; }
+        lo_w |= (uint32_t)ql << (8 * k);
+        hi_w |= (uint32_t)qh << (8 * k);
+      }
+      if (fits) {
+        nd.origin[a] = O;
+        nd.exp[a] = (uint8_t)e;
+        nd.lo[a] = lo_w;
+        nd.hi[a] = hi_w;
+        break;
+      }
+    }
+  }
+}
+
+struct Collapser {
+  const std::vector<BinNode> &bin;
+  std::vector<Node4> out;
+  int max_depth = 0;
+  explicit Collapser(const std::vector<BinNode> &b) : bin(b) {}
+
+  // Emits the four-wide node that replaces binary node `n2` and returns its index; sets
+  // *need to the most stack entries a walk below it can hold at once.
+  int32_t emit(int32_t n2, int depth, int *need) {
+    Box6 boxes[4];
+    int32_t refs[4];
+    int n = 2;
+    boxes[0] = bin[(size_t)n2].box[0]; refs[0] = bin[(size_t)n2].child[0];
+    boxes[1] = bin[(size_t)n2].box[1]; refs[1] = bin[(size_t)n2].child[1];
+    while (n < 4) {
+      // open the inner child with the largest surface: its two children take its place
+      int best = -1;
+      double bestArea = -1;
+      for (int k = 0; k < n; k++)
+        if (refs[k] >= 0 && boxes[k].area() > bestArea) { bestArea = boxes[k].area(); best = k; }
+      if (best < 0) break;
+      const BinNode &b = bin[(size_t)refs[best]];
+      boxes[best] = b.box[0]; refs[best] = b.child[0];
+      boxes[n] = b.box[1]; refs[n] = b.child[1];
+      n++;
+    }
+    // larger boxes first: an any-hit walk enters the first child it hits
+    for (int i = 1; i < n; i++)
+      for (int j = i; j > 0 && boxes[j].area() > boxes[j - 1].area(); j--) {
+        std::swap(boxes[j], boxes[j - 1]);
+        std::swap(refs[j], refs[j - 1]);
+      }
+    int32_t me = (int32_t)out.size();
+    out.emplace_back();
+    max_depth = std::max(max_depth, depth + 1);
+    int below = 0;
+    for (int k = 0; k < n; k++)
+      if (refs[k] >= 0) {
+        int nb = 0;
+        refs[k] = emit(refs[k], depth + 1, &nb);
+        below = std::max(below, nb);
+      }
+    quantise(out[(size_t)me], boxes, refs, n);
+    *need = (n - 1) + below;
     return me;
   }
 };
@@ -491,36 +587,36 @@ int build_host_scene(const mipt_scene_desc *d, HostScene *out, std::string *err)
   // ---- BVH over all primitives ---------------------------------------------------
   size_t nPrims = prims.size();
   Builder builder(prims);
+  if (const char *lm = std::getenv("MIPT_LEAF_MAX")) {  // tuning knob: preferred primitives per leaf
+    int v = std::atoi(lm);
+    if (v >= 1 && v <= kLeafHard) builder.leaf_max = v;
+  }
   builder.nodes.reserve(nPrims / 2 + 16);
   Box6 rootBox;
   rootBox.reset();
+  Collapser wide(builder.nodes);
+  int need = 0;
   if (nPrims == 0) {
-    Node nd;
-    std::memset(&nd, 0, sizeof(nd));
-    for (int a = 0; a < 3; a++) { nd.lmin[a] = nd.rmin[a] = 1.0f; nd.lmax[a] = nd.rmax[a] = -1.0f; }
-    nd.left = nd.right = ~0;
-    builder.nodes.push_back(nd);
-    builder.max_depth = 1;
+    Node4 nd;
+    quantise(nd, nullptr, nullptr, 0);
+    wide.out.push_back(nd);
+    wide.max_depth = 1;
   } else {
     int32_t root = builder.build(0, nPrims, 0, &rootBox);
     if (root < 0) {
-      // the whole scene fits one leaf: wrap it in a root node with an absent right child
-      Node nd;
-      std::memset(&nd, 0, sizeof(nd));
-      for (int a = 0; a < 3; a++) {
-        nd.lmin[a] = round_down(rootBox.mn[a]);
-        nd.lmax[a] = round_up(rootBox.mx[a]);
-        nd.rmin[a] = 1.0f;
-        nd.rmax[a] = -1.0f;
-      }
-      nd.left = root;
-      nd.right = ~0;
-      builder.nodes.push_back(nd);
-      builder.max_depth = 1;
+      // the whole scene fits one leaf: a root node with that single child
+      Node4 nd;
+      quantise(nd, &rootBox, &root, 1);
+      wide.out.push_back(nd);
+      wide.max_depth = 1;
+    } else {
+      wide.out.reserve(builder.nodes.size() / 2 + 16);
+      wide.emit(root, 0, &need);
     }
   }
-  S.nodes = std::move(builder.nodes);
-  S.max_depth = builder.max_depth;
+  S.nodes = std::move(wide.out);
+  S.max_depth = wide.max_depth;
+  S.stack_need = need + 1;
   S.tris.resize(nPrims);
   S.prim_info.resize(nPrims);
   S.ref_order.resize(nPrims);

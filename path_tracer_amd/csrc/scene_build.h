@@ -14,7 +14,7 @@ namespace mipt {
 struct HostScene {
   CameraRec camera;
   double ambient[3];
-  std::vector<Node> nodes;             // nodes[0] is the root
+  std::vector<Node4> nodes;            // nodes[0] is the root
   std::vector<Tri> tris;               // per primitive (leaf order); unused slots for analytic prims
   std::vector<TriNormals> tri_normals; // per primitive, empty if no mesh has vertex normals
   std::vector<uint32_t> prim_info;     // kind << 30 | object
@@ -23,7 +23,8 @@ struct HostScene {
   std::vector<MatRec> materials;
   std::vector<LightRec> lights;
   int rays_per_hit = 0;                // shadow rays per shaded hit for a given area_samples
-  int max_depth = 0;                   // deepest inner-node nesting (traversal stack bound)
+  int max_depth = 0;                   // deepest inner-node nesting
+  int stack_need = 0;                  // most entries a traversal can hold on its stack at once
   double radius = 0;                   // max |coordinate| of the scene bounds
   bool translucent = false;            // some material has kt != 0
   bool has_cubemap = false;

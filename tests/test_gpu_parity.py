@@ -86,6 +86,25 @@ def test_closest_hit_on_a_triangle_mesh_scene(gpu, oracle_lib):
     assert_rays_match(gpu.intersect(P + n[hit] * 1e-8, r), orc.intersect(P + n[hit] * 1e-8, r), min_same=0.9999)
 
 
+def test_traversal_stack_overflow_area(gpu, oracle_lib, monkeypatch):
+    # with two LDS entries per lane nearly every walk keeps the rest of its stack in the
+    # global-memory overflow area: closest hits, any-hit shadow rays and images must not change
+    from path_tracer_amd import synth
+
+    sc = synth.make_scene(20000, seed=11)
+    orc = oracle_lib.Oracle(sc)
+    monkeypatch.setenv("MIPT_LDS_STACK", "2")
+    upload(gpu, sc)
+    monkeypatch.delenv("MIPT_LDS_STACK")
+    org, d = U.camera_rays(sc, 20000, seed=5)
+    res = orc.intersect(org, d)
+    assert_rays_match(gpu.intersect(org, d), res, min_same=0.9999)
+    p = abi.default_params(96, 54, spp=2, seed=3)
+    f32, rgb8 = gpu.render(p)
+    ref, ref8 = orc.render(p, threads=8, want_rgb8=True)
+    assert_images_match(f32, ref, rgb8, ref8, frac=0.995)
+
+
 def test_transformed_mesh_matches_local_space_reference(gpu, oracle_lib):
     # the library pre-transforms triangles to world space; the reference intersects in the
     # mesh's local space (scene.cpp:13-40).  Non-uniform scale + rotation + mirroring.
