@@ -159,7 +159,10 @@ struct Cull {
 
 __device__ __forceinline__ void cull_axis(double o, double d, double R, float &id, float &offN, float &offF) {
   double dd = fabs(d) < 1e-30 ? copysign(1e-30, d) : d;
-  double inv = 1.0 / dd;
+  // 1/dd to ~1e-15 (hardware estimate + two Newton steps): it only feeds the fp32 culling
+  double inv = __builtin_amdgcn_rcp(dd);
+  inv = fma(fma(-dd, inv, 1.0), inv, inv);
+  inv = fma(fma(-dd, inv, 1.0), inv, inv);
   double oi = o * inv;
   double pad = 4.76837158203125e-07 * (R + fabs(o)) * fabs(inv);
   id = (float)inv;
@@ -230,54 +233,94 @@ __device__ __forceinline__ void trav_init(Trav &T, const SceneDev &S, d3 org, d3
 
 __device__ __forceinline__ float ubyte_f(uint32_t w, int k) { return (float)((w >> (8 * k)) & 0xffu); }  // v_cvt_f32_ubyteK
 
+#ifndef MIPT_MIN_DESCENDING
+#define MIPT_MIN_DESCENDING 16
+#endif
+constexpr int kMinDescending = MIPT_MIN_DESCENDING;
+
 #define MIPT_CSWAP(a, b)                                        \
   if (t[b] < t[a]) {                                            \
     float tt_ = t[a]; t[a] = t[b]; t[b] = tt_;                  \
     int cc_ = ch[a]; ch[a] = ch[b]; ch[b] = cc_;                \
   }
 
+// The children of inner node `node` the ray can enter: ch[k] = child reference, t[k] = entry
+// distance, or 3e38 where the ray misses the child's box or the child is absent.
+// The ray is moved into the node's quantised frame once (per axis
+// t = q * (step / d) + ((origin - o) / d -+ pad)), then each child costs six byte->float
+// conversions and six fmas.  The error of the extra fma stays inside the pad of make_cull
+// (about 2 of its 8 units of 2^-24 (R + |o|) |1/d| are used).
+__device__ __forceinline__ void node_test(const Trav &T, const SceneDev &S, int node, int ch[4], float t[4]) {
+  const uint4 *np = reinterpret_cast<const uint4 *>(S.nodes + node);
+  uint4 q0 = np[0], q1 = np[1], q2 = np[2];
+  int4 q3 = *reinterpret_cast<const int4 *>(np + 3);
+  const float ax = __uint_as_float((q0.w & 0xffu) << 23) * T.c.idx;
+  const float ay = __uint_as_float(((q0.w >> 8) & 0xffu) << 23) * T.c.idy;
+  const float az = __uint_as_float(((q0.w >> 16) & 0xffu) << 23) * T.c.idz;
+  const float ox = __uint_as_float(q0.x), oy = __uint_as_float(q0.y), oz = __uint_as_float(q0.z);
+  const float bnx = __fmaf_rn(ox, T.c.idx, T.c.nx), bfx = __fmaf_rn(ox, T.c.idx, T.c.fx);
+  const float bny = __fmaf_rn(oy, T.c.idy, T.c.ny), bfy = __fmaf_rn(oy, T.c.idy, T.c.fy);
+  const float bnz = __fmaf_rn(oz, T.c.idz, T.c.nz), bfz = __fmaf_rn(oz, T.c.idz, T.c.fz);
+  // the plane a ray enters through is the upper one on axes it travels down
+  const uint32_t nX = T.c.idx < 0.0f ? q1.w : q1.x, fX = T.c.idx < 0.0f ? q1.x : q1.w;
+  const uint32_t nY = T.c.idy < 0.0f ? q2.x : q1.y, fY = T.c.idy < 0.0f ? q1.y : q2.x;
+  const uint32_t nZ = T.c.idz < 0.0f ? q2.y : q1.z, fZ = T.c.idz < 0.0f ? q1.z : q2.y;
+  ch[0] = q3.x; ch[1] = q3.y; ch[2] = q3.z; ch[3] = q3.w;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    float tn = fmaxf(fmaxf(__fmaf_rn(ubyte_f(nX, k), ax, bnx), __fmaf_rn(ubyte_f(nY, k), ay, bny)),
+                     fmaxf(__fmaf_rn(ubyte_f(nZ, k), az, bnz), 0.0f));
+    float tf = fminf(fminf(__fmaf_rn(ubyte_f(fX, k), ax, bfx), __fmaf_rn(ubyte_f(fY, k), ay, bfy)),
+                     fminf(__fmaf_rn(ubyte_f(fZ, k), az, bfz), T.tlimit));
+    // one rounding of the last fma is left on each side: a relative 2^-22 slack covers it
+    t[k] = (tn <= tf * 1.0000005f && ch[k] != kNoChild) ? tn : 3.0e38f;
+  }
+}
+
+// Tests primitive `s` (storage index) against the ray.  Closest hit (ANY = false): keeps the
+// smallest (t, ref_order).  Any hit: every t < T.best.t counts.  Returns whether T.best changed.
+template <bool ANY>
+__device__ __forceinline__ bool prim_test(Trav &T, const SceneDev &S, uint32_t s) {
+  uint32_t info = S.prim_info[s];
+  uint32_t kind = info >> 30;
+  double t;
+  bool hit;
+  if (kind == KIND_TRI) {
+    double w1, w2;
+    hit = tri_hit(S.tris + s, T.org, T.dir, t, w1, w2);
+  } else {
+    d3 Nl;
+    hit = analytic_hit(S.objects + (info & 0x3fffffffu), kind, T.org, T.dir, t, Nl);
+  }
+  if (!hit) return false;
+  bool closer = t < T.best.t;
+  if (!ANY && t == T.best.t && T.best.prim >= 0) closer = S.ref_order[s] < S.ref_order[T.best.prim];
+  if (!closer) return false;
+  T.best.t = t;
+  T.best.prim = (int)s;
+  T.tlimit = __double2float_ru(t) * 1.0000005f;
+  return true;
+}
+
 // One round of the "while-while" walk: descend through inner nodes until the lane holds a
 // leaf (or is done), then test that leaf's primitives and pop the next node.  Keeping the
 // two phases apart lets the lanes of a wave run the fp64 primitive tests together instead
 // of paying for both bodies on every iteration.
-//
-// Inner node: the ray is moved into the node's quantised frame once (per axis
-// t = q * (step / d) + ((origin - o) / d -+ pad)), then each child costs six byte->float
-// conversions and six fmas.  The error of the extra fma stays inside the pad of make_cull
-// (about 2 of its 8 units of 2^-24 (R + |o|) |1/d| are used).
-// Closest hit (ANY = false): children are entered near to far, and the smallest
-// (t, ref_order) is kept.  Any hit (ANY = true): children are entered in slot order (the
-// builder puts large boxes first) and the first primitive with t < tmax ends the walk.
+// Closest hit (ANY = false): children are entered near to far.  Any hit (ANY = true):
+// children are entered in slot order (the builder puts large boxes first) and the first
+// primitive with t < tmax ends the walk.
 template <bool ANY, bool COUNT>
 __device__ __forceinline__ void trav_round(Trav &T, const SceneDev &S, const Stack &stk, TravCounters &tc) {
   int cur = T.cur, sp = T.sp;
   while (cur >= 0) {
-    const uint4 *np = reinterpret_cast<const uint4 *>(S.nodes + cur);
-    uint4 q0 = np[0], q1 = np[1], q2 = np[2];
-    int4 q3 = *reinterpret_cast<const int4 *>(np + 3);
-    if (COUNT) tc.nodes++;
-    const float ax = __uint_as_float((q0.w & 0xffu) << 23) * T.c.idx;
-    const float ay = __uint_as_float(((q0.w >> 8) & 0xffu) << 23) * T.c.idy;
-    const float az = __uint_as_float(((q0.w >> 16) & 0xffu) << 23) * T.c.idz;
-    const float ox = __uint_as_float(q0.x), oy = __uint_as_float(q0.y), oz = __uint_as_float(q0.z);
-    const float bnx = __fmaf_rn(ox, T.c.idx, T.c.nx), bfx = __fmaf_rn(ox, T.c.idx, T.c.fx);
-    const float bny = __fmaf_rn(oy, T.c.idy, T.c.ny), bfy = __fmaf_rn(oy, T.c.idy, T.c.fy);
-    const float bnz = __fmaf_rn(oz, T.c.idz, T.c.nz), bfz = __fmaf_rn(oz, T.c.idz, T.c.fz);
-    // the plane a ray enters through is the upper one on axes it travels down
-    const uint32_t nX = T.c.idx < 0.0f ? q1.w : q1.x, fX = T.c.idx < 0.0f ? q1.x : q1.w;
-    const uint32_t nY = T.c.idy < 0.0f ? q2.x : q1.y, fY = T.c.idy < 0.0f ? q1.y : q2.x;
-    const uint32_t nZ = T.c.idz < 0.0f ? q2.y : q1.z, fZ = T.c.idz < 0.0f ? q1.z : q2.y;
-    int ch[4] = {q3.x, q3.y, q3.z, q3.w};
+    int ch[4];
     float t[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-      float tn = fmaxf(fmaxf(__fmaf_rn(ubyte_f(nX, k), ax, bnx), __fmaf_rn(ubyte_f(nY, k), ay, bny)),
-                       fmaxf(__fmaf_rn(ubyte_f(nZ, k), az, bnz), 0.0f));
-      float tf = fminf(fminf(__fmaf_rn(ubyte_f(fX, k), ax, bfx), __fmaf_rn(ubyte_f(fY, k), ay, bfy)),
-                       fminf(__fmaf_rn(ubyte_f(fZ, k), az, bfz), T.tlimit));
-      // one rounding of the last fma is left on each side: a relative 2^-22 slack covers it
-      t[k] = (tn <= tf * 1.0000005f && ch[k] != kNoChild) ? tn : 3.0e38f;
-    }
+    node_test(T, S, cur, ch, t);
+#ifdef MIPT_LANE_STATS  // lane slots instead of visits: 64 per wave-level iteration
+    if (COUNT) { unsigned long long m_ = __ballot(1); if (__lane_id() == (unsigned)__ffsll((long long)m_) - 1u) tc.nodes += 64; }
+#else
+    if (COUNT) tc.nodes++;
+#endif
     if (!ANY) {
       MIPT_CSWAP(0, 1) MIPT_CSWAP(2, 3) MIPT_CSWAP(0, 2) MIPT_CSWAP(1, 3) MIPT_CSWAP(1, 2)
     }
@@ -295,35 +338,20 @@ __device__ __forceinline__ void trav_round(Trav &T, const SceneDev &S, const Sta
     if (have) cur = nxt;
     else if (sp == 0) cur = MIPT_TRAV_DONE;
     else cur = (int)stack_pop(S, stk, sp);
+    // few lanes left descending: let them pause so the others can go on with their leaves
+    if (kMinDescending > 0 && (int)__popcll(__ballot(cur >= 0)) < kMinDescending) break;
   }
-  if (cur != MIPT_TRAV_DONE) {
+  if (cur < 0 && cur != MIPT_TRAV_DONE) {
     uint32_t code = (uint32_t)~cur;
     uint32_t first = code >> 3, count = (code & 7u) + 1u;
     bool found = false;
     for (uint32_t k = 0; k < count; k++) {
-      uint32_t s = first + k;
-      uint32_t info = S.prim_info[s];
-      uint32_t kind = info >> 30;
-      double t;
-      bool hit;
+#ifdef MIPT_LANE_STATS
+      if (COUNT) { unsigned long long m_ = __ballot(1); if (__lane_id() == (unsigned)__ffsll((long long)m_) - 1u) tc.prims += 64; }
+#else
       if (COUNT) tc.prims++;
-      if (kind == KIND_TRI) {
-        double w1, w2;
-        hit = tri_hit(S.tris + s, T.org, T.dir, t, w1, w2);
-      } else {
-        d3 Nl;
-        hit = analytic_hit(S.objects + (info & 0x3fffffffu), kind, T.org, T.dir, t, Nl);
-      }
-      if (hit) {
-        bool closer = t < T.best.t;
-        if (!ANY && t == T.best.t && T.best.prim >= 0) closer = S.ref_order[s] < S.ref_order[T.best.prim];
-        if (closer) {
-          T.best.t = t;
-          T.best.prim = (int)s;
-          T.tlimit = __double2float_ru(t) * 1.0000005f;
-          if (ANY) { found = true; break; }
-        }
-      }
+#endif
+      if (prim_test<ANY>(T, S, first + k) && ANY) { found = true; break; }
     }
     if (found || sp == 0) cur = MIPT_TRAV_DONE;
     else cur = (int)stack_pop(S, stk, sp);

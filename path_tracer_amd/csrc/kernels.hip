@@ -173,7 +173,7 @@ __global__ void __launch_bounds__(kBlock) k_generate(SceneDev S, RenderConst rc,
 // numbers wave, wave + W, wave + 2W, ...), so there is no work counter to contend for and
 // rays that are neighbours in the queue still enter a wave together.
 #ifndef MIPT_REFILL_IDLE
-#define MIPT_REFILL_IDLE 20
+#define MIPT_REFILL_IDLE 32
 #endif
 constexpr uint32_t kRefillIdle = MIPT_REFILL_IDLE;
 
@@ -427,8 +427,9 @@ __device__ __forceinline__ ShadowSetup shadow_setup(const RenderConst &rc, const
     r.has_target = false;
   } else if (L.type == MIPT_LIGHT_POINT) {  // light.cpp:63-85
     r.target = ld3(L.position);
-    r.dir = normalize(r.target - fire);
-    r.lightT = sqrt(dot(r.target - fire, r.target - fire));
+    d3 to = r.target - fire;
+    r.lightT = sqrt(dot(to, to));
+    r.dir = to * (1.0 / r.lightT);  // normalize(to)
   } else {  // light.cpp:105-147
     double uI, vI;
     if (rc.flags & MIPT_FLAG_FIXED_AREA_PATTERN) {
@@ -442,9 +443,10 @@ __device__ __forceinline__ ShadowSetup shadow_setup(const RenderConst &rc, const
     // samplePoint: corner + uVec*uI + vVec + vI — vVec whole, vI on every component (light.cpp:109)
     d3 cu = (ld3(L.position) + ld3(L.u) * uI) + ld3(L.v);
     r.target = d3{cu.x + vI, cu.y + vI, cu.z + vI};
-    r.dir = normalize(r.target - fire);
-    r.lightT = sqrt(dot(r.target - fire, r.target - fire));
-    double dd = length(fire - r.target);
+    d3 to = r.target - fire;
+    r.lightT = sqrt(dot(to, to));
+    r.dir = to * (1.0 / r.lightT);  // normalize(to)
+    double dd = r.lightT;           // length(fire - target): the same squares, the same sum
     double denom = L.a + L.b * dd + L.c * (dd * dd);
     r.scale = fmin(1.0, 1 / denom);
   }
@@ -479,11 +481,11 @@ __device__ __forceinline__ int light_of_ray(const SceneDev &S, uint32_t r) {
 }
 
 // Any-hit shadow rays for opaque scenes, persistent waves with ray replacement (see
-// k_intersect).  Work item w = hit * rays_per_hit + ray: the rays of one hit are adjacent
-// and enter a wave together, so they share origin and target region.  Result per ray:
-// vis[w - first_item] = 0 if occluded, else the sample's attenuation scale.
+// k_intersect).  Work item w = hit * rays_per_hit + ray, hits counted from `first_hit`: the
+// rays of one hit are adjacent and enter a wave together, so they share origin and target
+// region.  Result per ray: vis[w] = 0 if occluded, else the sample's attenuation scale.
 template <bool COUNT>
-__global__ void __launch_bounds__(kBlock, MIPT_TRAV_WAVES) k_shadow_any(SceneDev S, RenderConst rc, ShadeList sl, uint64_t first_item, uint32_t n_items,
+__global__ void __launch_bounds__(kBlock, MIPT_TRAV_WAVES) k_shadow_any(SceneDev S, RenderConst rc, ShadeList sl, uint32_t first_hit, uint32_t n_items,
                                                                          double *__restrict__ vis, DeviceCounters *dc) {
   extern __shared__ uint32_t lds_stack[];
   const Stack stack{lds_stack + threadIdx.x, kBlock, blockIdx.x * kBlock + threadIdx.x};
@@ -507,9 +509,9 @@ __global__ void __launch_bounds__(kBlock, MIPT_TRAV_WAVES) k_shadow_any(SceneDev
         uint64_t it = wave_seq_item(next + rank_below(idle_mask, lane), wave, n_waves);
         if (it < n_items) {
           item = (uint32_t)it;
-          uint64_t w = first_item + it;
-          uint32_t h = (uint32_t)(w / R);
-          uint32_t r = (uint32_t)(w - (uint64_t)h * R);
+          uint32_t hl = item / R;  // hit within this launch
+          uint32_t r = item - hl * R;
+          uint32_t h = first_hit + hl;
           int li = light_of_ray(S, r);
           const LightRec &L = S.lights[li];
           d3 P{sl.px[h], sl.py[h], sl.pz[h]};
@@ -754,7 +756,7 @@ void launch_shadow_trace(const SceneDev &S, const RenderConst &rc, ShadeList sl,
     hipLaunchKernelGGL(kern, dim3(persistent_grid(rc, items)), dim3(kBlock), stack_bytes(S), st, S, rc, sl, first_hit * R, items, vis, dc);
   } else {
     auto kern = count ? k_shadow_any<true> : k_shadow_any<false>;
-    hipLaunchKernelGGL(kern, dim3(persistent_grid(rc, items)), dim3(kBlock), stack_bytes(S), st, S, rc, sl, first_hit * R, items, vis, dc);
+    hipLaunchKernelGGL(kern, dim3(persistent_grid(rc, items)), dim3(kBlock), stack_bytes(S), st, S, rc, sl, (uint32_t)first_hit, items, vis, dc);
   }
 }
 
