@@ -216,8 +216,13 @@ __device__ __forceinline__ void stack_push(const SceneDev &S, const Stack &st, i
 }
 __device__ __forceinline__ uint32_t stack_pop(const SceneDev &S, const Stack &st, int &sp) {
   sp--;
-  if (sp < S.stack_entries) return st.lds[sp * st.stride];
-  return S.stack_ovf[(size_t)(sp - S.stack_entries) * S.ovf_stride + st.gtid];
+  // always an LDS read (of the last LDS entry when the top of the stack is in the overflow
+  // area), so the common path stays a plain ds_read
+  int k = sp < S.stack_entries ? sp : S.stack_entries - 1;
+  uint32_t v = st.lds[k * st.stride];
+  asm volatile("" : "+v"(v));  // keeps the two reads apart: merged, they become one flat load through the texture path
+  if (sp >= S.stack_entries) v = S.stack_ovf[(size_t)(sp - S.stack_entries) * S.ovf_stride + st.gtid];
+  return v;
 }
 
 __device__ __forceinline__ void trav_init(Trav &T, const SceneDev &S, d3 org, d3 dir, double tmax) {
@@ -324,18 +329,26 @@ __device__ __forceinline__ void trav_round(Trav &T, const SceneDev &S, const Sta
     if (!ANY) {
       MIPT_CSWAP(0, 1) MIPT_CSWAP(2, 3) MIPT_CSWAP(0, 2) MIPT_CSWAP(1, 3) MIPT_CSWAP(1, 2)
     }
-    // enter the first child that was hit, stack the others (last first)
-    int nxt = MIPT_TRAV_DONE;
-    bool have = false;
-#pragma unroll
-    for (int k = 3; k >= 0; k--) {
-      if (t[k] < 2.0e38f) {
-        if (have) stack_push(S, stk, sp, (uint32_t)nxt);
-        nxt = ch[k];
-        have = true;
-      }
+    // enter the first child that was hit, stack the others so that they pop in order
+    const bool h0 = t[0] < 2.0e38f, h1 = t[1] < 2.0e38f, h2 = t[2] < 2.0e38f, h3 = t[3] < 2.0e38f;
+    // sorted (closest hit): the hits are the first entries, so child k >= 1 is stacked iff hit
+    const bool p1 = ANY ? (h1 && h0) : h1;
+    const bool p2 = ANY ? (h2 && (h0 || h1)) : h2;
+    const bool p3 = ANY ? (h3 && (h0 || h1 || h2)) : h3;
+    const int enter = h0 ? ch[0] : h1 ? ch[1] : h2 ? ch[2] : ch[3];
+    if (sp + 3 <= S.stack_entries) {  // all in LDS: three predicated writes, no inner branches
+      if (p3) stk.lds[sp * stk.stride] = (uint32_t)ch[3];
+      const int s2 = sp + (p3 ? 1 : 0);
+      if (p2) stk.lds[s2 * stk.stride] = (uint32_t)ch[2];
+      const int s1 = s2 + (p2 ? 1 : 0);
+      if (p1) stk.lds[s1 * stk.stride] = (uint32_t)ch[1];
+      sp = s1 + (p1 ? 1 : 0);
+    } else {
+      if (p3) stack_push(S, stk, sp, (uint32_t)ch[3]);
+      if (p2) stack_push(S, stk, sp, (uint32_t)ch[2]);
+      if (p1) stack_push(S, stk, sp, (uint32_t)ch[1]);
     }
-    if (have) cur = nxt;
+    if (h0 || h1 || h2 || h3) cur = enter;
     else if (sp == 0) cur = MIPT_TRAV_DONE;
     else cur = (int)stack_pop(S, stk, sp);
     // few lanes left descending: let them pause so the others can go on with their leaves
