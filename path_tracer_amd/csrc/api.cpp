@@ -347,6 +347,7 @@ int mipt_upload_scene(mipt_ctx *c, const mipt_scene_desc *desc) {
   D.n_lights = (int)H.lights.size();
   D.n_materials = (int)H.materials.size();
   D.n_prims = (int)H.prim_info.size();
+  D.n_analytic = H.n_analytic;
   // traversal stacks: up to kLdsStackMax entries per lane in LDS (6 blocks x 256 lanes x 24
   // entries fill 144 of a CU's 160 KB), the rest of the worst case in global memory
   const int kLdsStackMax = 24;

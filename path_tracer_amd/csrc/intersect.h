@@ -31,6 +31,7 @@ struct SceneDev {
   int n_lights;
   int n_materials;
   int n_prims;
+  int n_analytic;  // primitives [0, n_analytic) are analytic, [n_analytic, n_prims) triangles
   int rays_per_hit;
   int stack_entries;  // LDS traversal stack entries per lane; deeper entries go to stack_ovf
   uint32_t *stack_ovf;     // overflow of the traversal stacks: entry k of thread g at [k * ovf_stride + g]
@@ -286,16 +287,15 @@ __device__ __forceinline__ void node_test(const Trav &T, const SceneDev &S, int 
 // smallest (t, ref_order).  Any hit: every t < T.best.t counts.  Returns whether T.best changed.
 template <bool ANY>
 __device__ __forceinline__ bool prim_test(Trav &T, const SceneDev &S, uint32_t s) {
-  uint32_t info = S.prim_info[s];
-  uint32_t kind = info >> 30;
   double t;
   bool hit;
-  if (kind == KIND_TRI) {
+  if (s >= (uint32_t)S.n_analytic) {
     double w1, w2;
     hit = tri_hit(S.tris + s, T.org, T.dir, t, w1, w2);
   } else {
+    uint32_t info = S.prim_info[s];
     d3 Nl;
-    hit = analytic_hit(S.objects + (info & 0x3fffffffu), kind, T.org, T.dir, t, Nl);
+    hit = analytic_hit(S.objects + (info & 0x3fffffffu), info >> 30, T.org, T.dir, t, Nl);
   }
   if (!hit) return false;
   bool closer = t < T.best.t;

@@ -586,6 +586,9 @@ int build_host_scene(const mipt_scene_desc *d, HostScene *out, std::string *err)
 
   // ---- BVH over all primitives ---------------------------------------------------
   size_t nPrims = prims.size();
+  size_t nAnalytic = (size_t)(std::stable_partition(prims.begin(), prims.end(), [&](const BuildPrim &p) { return (infoRef[p.id] >> 30) != KIND_TRI; }) -
+                              prims.begin());
+  S.n_analytic = (int)nAnalytic;
   Builder builder(prims);
   if (const char *lm = std::getenv("MIPT_LEAF_MAX")) {  // tuning knob: preferred primitives per leaf
     int v = std::atoi(lm);
@@ -602,7 +605,25 @@ int build_host_scene(const mipt_scene_desc *d, HostScene *out, std::string *err)
     wide.out.push_back(nd);
     wide.max_depth = 1;
   } else {
-    int32_t root = builder.build(0, nPrims, 0, &rootBox);
+    // analytic primitives and triangles get subtrees of their own, joined at the root: the
+    // kernels then know a primitive's kind from its storage index alone
+    int32_t root;
+    if (nAnalytic == 0 || nAnalytic == nPrims) {
+      root = builder.build(0, nPrims, 0, &rootBox);
+    } else {
+      Box6 ba, bt;
+      int32_t me = (int32_t)builder.nodes.size();
+      builder.nodes.emplace_back();
+      builder.max_depth = 1;
+      int32_t ra = builder.build(0, nAnalytic, 1, &ba);
+      int32_t rt = builder.build(nAnalytic, nPrims, 1, &bt);
+      BinNode &nd = builder.nodes[(size_t)me];
+      nd.box[0] = ba; nd.box[1] = bt;
+      nd.child[0] = ra; nd.child[1] = rt;
+      rootBox = ba;
+      rootBox.grow(bt);
+      root = me;
+    }
     if (root < 0) {
       // the whole scene fits one leaf: a root node with that single child
       Node4 nd;
