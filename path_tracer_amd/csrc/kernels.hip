@@ -5,8 +5,8 @@
 //   shade     : Russian roulette, bounce and mirror rays, BRDF terms that need no
 //               shadow ray, queue compaction   (RayTracer::tracePath, RayTracer.cpp:221-306;
 //                                               Material::shadeBRDF, material.cpp:88-170)
-//   shadow    : one lane per shadow ray, in-wave segmented sum per hit
-//                                              (Light::shadowAttenuation, light.cpp:15-147)
+//   shadow    : one lane per shadow ray, one result per ray; a second kernel sums the
+//               rays of each hit                (Light::shadowAttenuation, light.cpp:15-147)
 //   resolve   : per-sample clamp and per-pixel sum (RayTracer.cpp:54,75)
 //   finalize  : mean and 8-bit truncation      (RayTracer.cpp:75,97-99)
 //
