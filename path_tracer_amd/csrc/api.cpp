@@ -470,15 +470,17 @@ int mipt_render_accumulate(mipt_ctx *c, const mipt_params *p, double *d_sum, voi
       int cur = 0;
       uint64_t spilled = 0;  // entries on the overflow stack
       const uint32_t chunk = (uint32_t)batch;  // rays per launch; children of one launch always fit a queue
+      uint32_t dup = (uint32_t)ns;             // the camera rays of a pixel's samples are identical
       while (n > 0) {
         HIP_TRY(c, hipMemsetAsync(bc, 0, sizeof(BatchCounts), st));
         {
           ProfScope ps(c, prof, MIPT_K_INTERSECT, n, st);
-          launch_intersect(c->dev, rc, q[cur], n, hit_t, hit_prim, dc, count, st);
+          launch_intersect(c->dev, rc, q[cur], n, dup, hit_t, hit_prim, dc, count, st);
         }
         {
           ProfScope ps(c, prof, MIPT_K_SHADE, n, st);
-          launch_shade(c->dev, rc, q[cur], n, hit_t, hit_prim, q[cur ^ 1], sl, bc, accum, dc, count, st);
+          launch_shade(c->dev, rc, q[cur], n, dup, hit_t, hit_prim, q[cur ^ 1], sl, bc, accum, dc, count, st);
+          dup = 1;
         }
         BatchCounts h;
         HIP_TRY(c, hipMemcpyAsync(&h, bc, sizeof(h), hipMemcpyDeviceToHost, st));

@@ -56,9 +56,11 @@ struct RenderConst {
 
 void launch_generate(const SceneDev &S, const RenderConst &rc, const int *rows, int64_t first_pixel, int n_pixels,
                      int sample0, int n_samples, RayQueue q, hipStream_t st);
-void launch_intersect(const SceneDev &S, const RenderConst &rc, RayQueue q, uint32_t n, double *hit_t, int *hit_prim,
+// dup > 1: the queue holds runs of `dup` identical rays; one ray per run is traced and the
+// whole run is shaded with its result (n must be a multiple of dup, else dup is ignored).
+void launch_intersect(const SceneDev &S, const RenderConst &rc, RayQueue q, uint32_t n, uint32_t dup, double *hit_t, int *hit_prim,
                       DeviceCounters *dc, bool count, hipStream_t st);
-void launch_shade(const SceneDev &S, const RenderConst &rc, RayQueue q, uint32_t n, const double *hit_t,
+void launch_shade(const SceneDev &S, const RenderConst &rc, RayQueue q, uint32_t n, uint32_t dup, const double *hit_t,
                   const int *hit_prim, RayQueue next, ShadeList sl, BatchCounts *bc, double *accum,
                   DeviceCounters *dc, bool count, hipStream_t st);
 void launch_copy_rays(RayQueue src, uint64_t src_off, RayQueue dst, uint64_t dst_off, uint32_t n, hipStream_t st);

@@ -184,9 +184,12 @@ __device__ __forceinline__ uint32_t rank_below(unsigned long long mask, uint32_t
   return (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
 }
 
+// `dup` > 1: the queue holds runs of `dup` identical rays (the camera rays of one pixel's
+// samples, RayTracer.cpp:72-75 calls trace(x, y) N times with the same x, y); only the first
+// ray of every run is traced, k_shade reads its result for the whole run.  n = rays to trace.
 template <bool COUNT>
-__global__ void __launch_bounds__(kBlock, MIPT_TRAV_WAVES) k_intersect(SceneDev S, RenderConst rc, RayQueue q, uint32_t n, double *__restrict__ hit_t,
-                                                                        int *__restrict__ hit_prim, DeviceCounters *dc) {
+__global__ void __launch_bounds__(kBlock, MIPT_TRAV_WAVES) k_intersect(SceneDev S, RenderConst rc, RayQueue q, uint32_t n, uint32_t dup,
+                                                                        double *__restrict__ hit_t, int *__restrict__ hit_prim, DeviceCounters *dc) {
   extern __shared__ uint32_t lds_stack[];
   const Stack stack{lds_stack + threadIdx.x, kBlock, blockIdx.x * kBlock + threadIdx.x};
   const uint32_t lane = lane_id();
@@ -206,7 +209,7 @@ __global__ void __launch_bounds__(kBlock, MIPT_TRAV_WAVES) k_intersect(SceneDev 
       if (idle) {
         uint64_t item = wave_seq_item(next + rank_below(idle_mask, lane), wave, n_waves);
         if (item < n) {
-          ray = (uint32_t)item;
+          ray = (uint32_t)item * dup;
           d3 o{q.ox[ray], q.oy[ray], q.oz[ray]};
           d3 d{q.dx[ray], q.dy[ray], q.dz[ray]};
           trav_init(T, S, o, d, rc.t_max);
@@ -239,7 +242,7 @@ __global__ void __launch_bounds__(kBlock, MIPT_TRAV_WAVES) k_intersect(SceneDev 
 #endif
 constexpr int kShadeBlock = MIPT_SHADE_BLOCK;
 template <bool COUNT>
-__global__ void __launch_bounds__(kShadeBlock) k_shade(SceneDev S, RenderConst rc, RayQueue q, uint32_t n, const double *__restrict__ hit_t,
+__global__ void __launch_bounds__(kShadeBlock) k_shade(SceneDev S, RenderConst rc, RayQueue q, uint32_t n, uint32_t dup, const double *__restrict__ hit_t,
                                                    const int *__restrict__ hit_prim, RayQueue nq, ShadeList sl, BatchCounts *bc,
                                                    double *accum, DeviceCounters *dc) {
   uint32_t idx = blockIdx.x * kShadeBlock + threadIdx.x;
@@ -251,7 +254,8 @@ __global__ void __launch_bounds__(kShadeBlock) k_shade(SceneDev S, RenderConst r
   int depth = 0;
   bool shaded = false;
   if (live) {
-    int prim = hit_prim[idx];
+    const uint32_t hidx = dup > 1u ? idx - idx % dup : idx;  // the run's traced ray
+    int prim = hit_prim[hidx];
     d3 o{q.ox[idx], q.oy[idx], q.oz[idx]};
     d3 d{q.dx[idx], q.dy[idx], q.dz[idx]};
     d3 T{q.tx[idx], q.ty[idx], q.tz[idx]};
@@ -265,7 +269,7 @@ __global__ void __launch_bounds__(kShadeBlock) k_shade(SceneDev S, RenderConst r
       double u0 = u01(mix64(key, SLOT_RR));
       if (!(u0 < rc.rr_q)) {  // RayTracer.cpp:228-231
         shaded = true;
-        double t = hit_t[idx];
+        double t = hit_t[hidx];
         N = hit_normal(S, prim, o, d);
         P = o + t * d;  // r.at(i)
         const ObjRec *ob = S.objects + (S.prim_info[prim] & 0x3fffffffu);
@@ -710,22 +714,21 @@ static inline unsigned persistent_grid(const RenderConst &rc, uint64_t n) {
   return (unsigned)(full < cap ? full : cap);
 }
 
-void launch_intersect(const SceneDev &S, const RenderConst &rc, RayQueue q, uint32_t n, double *hit_t, int *hit_prim, DeviceCounters *dc,
-                      bool count, hipStream_t st) {
+void launch_intersect(const SceneDev &S, const RenderConst &rc, RayQueue q, uint32_t n, uint32_t dup, double *hit_t, int *hit_prim,
+                      DeviceCounters *dc, bool count, hipStream_t st) {
   if (!n) return;
-  if (count)
-    hipLaunchKernelGGL(k_intersect<true>, dim3(persistent_grid(rc, n)), dim3(kBlock), stack_bytes(S), st, S, rc, q, n, hit_t, hit_prim, dc);
-  else
-    hipLaunchKernelGGL(k_intersect<false>, dim3(persistent_grid(rc, n)), dim3(kBlock), stack_bytes(S), st, S, rc, q, n, hit_t, hit_prim, dc);
+  if (dup < 1u || n % dup != 0u) dup = 1u;
+  uint32_t traced = n / dup;
+  auto kern = count ? k_intersect<true> : k_intersect<false>;
+  hipLaunchKernelGGL(kern, dim3(persistent_grid(rc, traced)), dim3(kBlock), stack_bytes(S), st, S, rc, q, traced, dup, hit_t, hit_prim, dc);
 }
 
-void launch_shade(const SceneDev &S, const RenderConst &rc, RayQueue q, uint32_t n, const double *hit_t, const int *hit_prim,
+void launch_shade(const SceneDev &S, const RenderConst &rc, RayQueue q, uint32_t n, uint32_t dup, const double *hit_t, const int *hit_prim,
                   RayQueue next, ShadeList sl, BatchCounts *bc, double *accum, DeviceCounters *dc, bool count, hipStream_t st) {
   if (!n) return;
-  if (count)
-    hipLaunchKernelGGL(k_shade<true>, dim3((n + kShadeBlock - 1) / kShadeBlock), dim3(kShadeBlock), 0, st, S, rc, q, n, hit_t, hit_prim, next, sl, bc, accum, dc);
-  else
-    hipLaunchKernelGGL(k_shade<false>, dim3((n + kShadeBlock - 1) / kShadeBlock), dim3(kShadeBlock), 0, st, S, rc, q, n, hit_t, hit_prim, next, sl, bc, accum, dc);
+  if (dup < 1u || n % dup != 0u) dup = 1u;
+  auto kern = count ? k_shade<true> : k_shade<false>;
+  hipLaunchKernelGGL(kern, dim3((n + kShadeBlock - 1) / kShadeBlock), dim3(kShadeBlock), 0, st, S, rc, q, n, dup, hit_t, hit_prim, next, sl, bc, accum, dc);
 }
 
 // Moves `n` ray records between queues (spill to / refill from the overflow stack).
