@@ -11,11 +11,14 @@
 #include "scene_build.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <future>
 #include <limits>
+#include <memory>
 
 namespace mipt {
 namespace {
@@ -142,40 +145,117 @@ struct Builder {
   std::vector<BinNode> nodes;
   int max_depth = 0;
   int leaf_max = kLeafMax;
+  int forks = 0;  // levels of the recursion that still build their two halves on two threads
   explicit Builder(std::vector<BuildPrim> &p) : prims(p) {}
+
+  // Appends the nodes of a finished sub-builder; returns the offset its indices moved by.
+  int32_t splice(const Builder &sub) {
+    int32_t off = (int32_t)nodes.size();
+    for (BinNode nd : sub.nodes) {
+      if (nd.child[0] >= 0) nd.child[0] += off;
+      if (nd.child[1] >= 0) nd.child[1] += off;
+      nodes.push_back(nd);
+    }
+    max_depth = std::max(max_depth, sub.max_depth);
+    return off;
+  }
 
   static int32_t leaf_code(size_t first, size_t count) { return ~(int32_t)((first << 3) | (count - 1)); }
 
   // Builds [b, e); returns the child reference and fills `bounds`.
   int32_t build(size_t b, size_t e, int depth, Box6 *bounds) {
     size_t n = e - b;
+    // large ranges near the root are scanned by several threads, each on a slice of its own
+    const int slices = (forks > 0 && n >= ((size_t)1 << 17)) ? 8 : 1;
+    auto slice_of = [&](int k, size_t *sb, size_t *se) {
+      *sb = b + n * (size_t)k / (size_t)slices;
+      *se = b + n * (size_t)(k + 1) / (size_t)slices;
+    };
+    struct Bounds { Box6 bb, cb; };
+    auto scan_bounds = [&](size_t sb, size_t se) {
+      Bounds r;
+      r.bb.reset();
+      r.cb.reset();
+      for (size_t i = sb; i < se; i++) {
+        r.bb.grow(prims[i].box);
+        r.cb.grow(D3{prims[i].c[0], prims[i].c[1], prims[i].c[2]});
+      }
+      return r;
+    };
     Box6 bb, cb;
     bb.reset();
     cb.reset();
-    for (size_t i = b; i < e; i++) {
-      bb.grow(prims[i].box);
-      cb.grow(D3{prims[i].c[0], prims[i].c[1], prims[i].c[2]});
+    {
+      std::vector<std::future<Bounds>> parts;
+      for (int k = 1; k < slices; k++) {
+        size_t sb, se;
+        slice_of(k, &sb, &se);
+        parts.push_back(std::async(std::launch::async, scan_bounds, sb, se));
+      }
+      size_t sb, se;
+      slice_of(0, &sb, &se);
+      Bounds r = scan_bounds(sb, se);
+      bb = r.bb;
+      cb = r.cb;
+      for (auto &f : parts) {
+        Bounds q = f.get();
+        bb.grow(q.bb);
+        cb.grow(q.cb);
+      }
     }
     *bounds = bb;
     if (n <= (size_t)leaf_max) return leaf_code(b, n);
 
-    // binned SAH over the three axes
+    // binned SAH over the three axes, one pass over the primitives
+    struct Bins { Box6 box[3][kBins]; size_t cnt[3][kBins]; };
+    double lo3[3], scale3[3];
+    bool use[3];
+    for (int axis = 0; axis < 3; axis++) {
+      lo3[axis] = cb.mn[axis];
+      use[axis] = cb.mx[axis] > cb.mn[axis];
+      scale3[axis] = use[axis] ? kBins / (cb.mx[axis] - cb.mn[axis]) : 0.0;
+    }
+    auto scan_bins = [&](size_t sb, size_t se) {
+      std::unique_ptr<Bins> r(new Bins);
+      for (int axis = 0; axis < 3; axis++)
+        for (int k = 0; k < kBins; k++) { r->box[axis][k].reset(); r->cnt[axis][k] = 0; }
+      for (size_t i = sb; i < se; i++)
+        for (int axis = 0; axis < 3; axis++) {
+          if (!use[axis]) continue;
+          int k = (int)((prims[i].c[axis] - lo3[axis]) * scale3[axis]);
+          if (k < 0) k = 0;
+          if (k >= kBins) k = kBins - 1;
+          r->box[axis][k].grow(prims[i].box);
+          r->cnt[axis][k]++;
+        }
+      return r;
+    };
+    std::unique_ptr<Bins> bins;
+    {
+      std::vector<std::future<std::unique_ptr<Bins>>> parts;
+      for (int k = 1; k < slices; k++) {
+        size_t sb, se;
+        slice_of(k, &sb, &se);
+        parts.push_back(std::async(std::launch::async, scan_bins, sb, se));
+      }
+      size_t sb, se;
+      slice_of(0, &sb, &se);
+      bins = scan_bins(sb, se);
+      for (auto &f : parts) {
+        std::unique_ptr<Bins> q = f.get();
+        for (int axis = 0; axis < 3; axis++)
+          for (int k = 0; k < kBins; k++) {
+            if (q->cnt[axis][k]) bins->box[axis][k].grow(q->box[axis][k]);
+            bins->cnt[axis][k] += q->cnt[axis][k];
+          }
+      }
+    }
     double bestCost = std::numeric_limits<double>::infinity();
     int bestAxis = -1, bestSplit = -1;
     for (int axis = 0; axis < 3; axis++) {
-      double lo = cb.mn[axis], hi = cb.mx[axis];
-      if (!(hi > lo)) continue;
-      double scale = kBins / (hi - lo);
-      Box6 binBox[kBins];
-      size_t binCnt[kBins];
-      for (int k = 0; k < kBins; k++) { binBox[k].reset(); binCnt[k] = 0; }
-      for (size_t i = b; i < e; i++) {
-        int k = (int)((prims[i].c[axis] - lo) * scale);
-        if (k < 0) k = 0;
-        if (k >= kBins) k = kBins - 1;
-        binBox[k].grow(prims[i].box);
-        binCnt[k]++;
-      }
+      if (!use[axis]) continue;
+      const Box6 *binBox = bins->box[axis];
+      const size_t *binCnt = bins->cnt[axis];
       double rightArea[kBins];
       size_t rightCnt[kBins];
       Box6 acc;
@@ -220,8 +300,24 @@ struct Builder {
     nodes.emplace_back();
     max_depth = std::max(max_depth, depth + 1);
     Box6 lb, rb;
-    int32_t l = build(b, mid, depth + 1, &lb);
-    int32_t r = build(mid, e, depth + 1, &rb);
+    int32_t l, r;
+    if (forks > 0 && n >= ((size_t)1 << 13)) {
+      // the halves work on disjoint ranges of `prims`; each builds into a node array of its own,
+      // spliced in afterwards in the order the sequential recursion allocates (left, then right)
+      Builder L(prims), R(prims);
+      L.leaf_max = R.leaf_max = leaf_max;
+      L.forks = R.forks = forks - 1;
+      auto left = std::async(std::launch::async, [&]() { return L.build(b, mid, depth + 1, &lb); });
+      r = R.build(mid, e, depth + 1, &rb);
+      l = left.get();
+      int32_t offL = splice(L);
+      if (l >= 0) l += offL;
+      int32_t offR = splice(R);
+      if (r >= 0) r += offR;
+    } else {
+      l = build(b, mid, depth + 1, &lb);
+      r = build(mid, e, depth + 1, &rb);
+    }
     BinNode &nd = nodes[(size_t)me];
     nd.box[0] = lb;
     nd.box[1] = rb;
@@ -375,7 +471,21 @@ void reference_visit_order(const std::vector<double> &boxes, std::vector<uint32_
   }
 }
 
+namespace {
+// MIPT_BUILD_TIMING=1 prints the time of each build phase to stderr.
+struct PhaseTimer {
+  bool on = std::getenv("MIPT_BUILD_TIMING") != nullptr;
+  std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+  void lap(const char *what) {
+    auto n = std::chrono::steady_clock::now();
+    if (on) std::fprintf(stderr, "[mipt build] %-28s %8.3f s\n", what, std::chrono::duration<double>(n - t).count());
+    t = n;
+  }
+};
+}  // namespace
+
 int build_host_scene(const mipt_scene_desc *d, HostScene *out, std::string *err) {
+  PhaseTimer timer;
   HostScene &S = *out;
   S = HostScene();
   auto fail = [&](int code, const char *msg) { *err = msg; return code; };
@@ -540,7 +650,14 @@ int build_host_scene(const mipt_scene_desc *d, HostScene *out, std::string *err)
     std::vector<uint32_t> fOrder;
     reference_visit_order(fboxes, &fOrder);
     if (prims.size() + faces.size() >= ((size_t)1 << 28)) return fail(MIPT_ERR_LIMIT, "too many primitives (limit 2^28-1)");
-    for (size_t q = 0; q < fOrder.size(); q++) {
+    // every face fills its own slots: slices of the faces go to threads
+    const size_t base = prims.size(), nf = fOrder.size();
+    prims.resize(base + nf);
+    trisRef.resize(base + nf);
+    if (anySmooth) normsRef.resize(base + nf);
+    infoRef.resize(base + nf);
+    auto do_faces = [&](size_t q0, size_t q1) {
+    for (size_t q = q0; q < q1; q++) {
       int64_t f = faces[fOrder[q]];
       int ia = m.faces[3 * f], ib = m.faces[3 * f + 1], ic = m.faces[3 * f + 2];
       D3 A{m.vertices[3 * ia], m.vertices[3 * ia + 1], m.vertices[3 * ia + 2]};
@@ -564,9 +681,9 @@ int build_host_scene(const mipt_scene_desc *d, HostScene *out, std::string *err)
       bp.box.reset();
       bp.box.grow(a); bp.box.grow(b); bp.box.grow(c);
       for (int ax = 0; ax < 3; ax++) bp.c[ax] = 0.5 * (bp.box.mn[ax] + bp.box.mx[ax]);
-      bp.id = (uint32_t)prims.size();
-      prims.push_back(bp);
-      trisRef.push_back(t);
+      bp.id = (uint32_t)(base + q);
+      prims[base + q] = bp;
+      trisRef[base + q] = t;
       if (anySmooth) {
         TriNormals tn;
         std::memset(&tn, 0, sizeof(tn));
@@ -578,12 +695,21 @@ int build_host_scene(const mipt_scene_desc *d, HostScene *out, std::string *err)
           tn.nb[0] = nb.x; tn.nb[1] = nb.y; tn.nb[2] = nb.z;
           tn.nc[0] = nc.x; tn.nc[1] = nc.y; tn.nc[2] = nc.z;
         }
-        normsRef.push_back(tn);
+        normsRef[base + q] = tn;
       }
-      infoRef.push_back(make_prim_info(KIND_TRI, oi));
+      infoRef[base + q] = make_prim_info(KIND_TRI, oi);
+    }
+    };
+    {
+      const size_t slices = nf >= ((size_t)1 << 16) ? 16 : 1;
+      std::vector<std::future<void>> parts;
+      for (size_t k = 1; k < slices; k++) parts.push_back(std::async(std::launch::async, do_faces, nf * k / slices, nf * (k + 1) / slices));
+      do_faces(0, nf / slices);
+      for (auto &f : parts) f.get();
     }
   }
 
+  timer.lap("primitives, reference order");
   // ---- BVH over all primitives ---------------------------------------------------
   size_t nPrims = prims.size();
   size_t nAnalytic = (size_t)(std::stable_partition(prims.begin(), prims.end(), [&](const BuildPrim &p) { return (infoRef[p.id] >> 30) != KIND_TRI; }) -
@@ -595,9 +721,11 @@ int build_host_scene(const mipt_scene_desc *d, HostScene *out, std::string *err)
     if (v >= 1 && v <= kLeafHard) builder.leaf_max = v;
   }
   builder.nodes.reserve(nPrims / 2 + 16);
+  builder.forks = 6;  // up to 64 tasks: SAH splits are uneven, many small tasks balance the threads
   Box6 rootBox;
   rootBox.reset();
   Collapser wide(builder.nodes);
+  timer.lap("partition by kind");
   int need = 0;
   if (nPrims == 0) {
     Node4 nd;
@@ -624,6 +752,7 @@ int build_host_scene(const mipt_scene_desc *d, HostScene *out, std::string *err)
       rootBox.grow(bt);
       root = me;
     }
+    timer.lap("binary SAH build");
     if (root < 0) {
       // the whole scene fits one leaf: a root node with that single child
       Node4 nd;
@@ -635,6 +764,7 @@ int build_host_scene(const mipt_scene_desc *d, HostScene *out, std::string *err)
       wide.emit(root, 0, &need);
     }
   }
+  timer.lap("collapse + quantise");
   S.nodes = std::move(wide.out);
   S.max_depth = wide.max_depth;
   S.stack_need = need + 1;
@@ -649,6 +779,7 @@ int build_host_scene(const mipt_scene_desc *d, HostScene *out, std::string *err)
     S.ref_order[s] = id;
     if (anySmooth) S.tri_normals[s] = normsRef[id];
   }
+  timer.lap("leaf-order arrays");
   double R = 0;
   if (nPrims)
     for (int a = 0; a < 3; a++) R = std::max(R, std::max(std::fabs(rootBox.mn[a]), std::fabs(rootBox.mx[a])));
