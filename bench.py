@@ -118,6 +118,8 @@ def main():
     ap.add_argument("--batch-samples", type=int, default=1 << 26)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo rehearses the N>1 path with several ranks on one GPU (RCCL needs one GPU per rank)")
     args = ap.parse_args()
 
     import torch
@@ -134,9 +136,14 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus} (WORLD_SIZE={world})")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the render path has no CPU fallback")
+    if args.backend == "gloo":
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend="gloo")
 
     scene, w, h, nominal_spp, label = build_scene(args.workload, args.triangles)
     ctx = Context(local_rank)
