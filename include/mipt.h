@@ -167,8 +167,10 @@ typedef struct mipt_params {
   int32_t sample_begin;
   int32_t sample_end;
   int32_t batch_samples; /* path samples per wavefront batch (also the most
-                            rays one kernel launch takes); 0 = default 2^22,
-                            at most 2^28                                       */
+                            rays one kernel launch takes); 0 = default 2^24,
+                            at most 2^28.  The workspace takes about 600 bytes
+                            of device memory per sample of a batch plus 16 per
+                            shadow ray of its widest level                    */
 } mipt_params;
 
 /* Work counters (summed over everything rendered since the last reset). */

@@ -418,7 +418,7 @@ int mipt_render_accumulate(mipt_ctx *c, const mipt_params *p, double *d_sum, voi
   if (owned == 0 || ns_total == 0) return MIPT_OK;
 
   // batch geometry: SB samples of PB pixels per batch, PB*SB <= B
-  int64_t B = p->batch_samples > 0 ? p->batch_samples : (1ll << 22);
+  int64_t B = p->batch_samples > 0 ? p->batch_samples : (1ll << 24);
   int SB = (int)std::min<int64_t>(ns_total, B);
   int64_t PB = std::max<int64_t>(1, B / SB);
   PB = std::min<int64_t>(PB, owned);

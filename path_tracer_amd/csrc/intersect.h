@@ -239,10 +239,13 @@ __device__ __forceinline__ void trav_init(Trav &T, const SceneDev &S, d3 org, d3
 
 __device__ __forceinline__ float ubyte_f(uint32_t w, int k) { return (float)((w >> (8 * k)) & 0xffu); }  // v_cvt_f32_ubyteK
 
-#ifndef MIPT_MIN_DESCENDING
-#define MIPT_MIN_DESCENDING 16
+// The descend loop of a round is left when fewer lanes than this are still in it.
+#ifndef MIPT_MIN_DESC_CLOSEST
+#define MIPT_MIN_DESC_CLOSEST 16
 #endif
-constexpr int kMinDescending = MIPT_MIN_DESCENDING;
+#ifndef MIPT_MIN_DESC_ANY
+#define MIPT_MIN_DESC_ANY 16
+#endif
 
 #define MIPT_CSWAP(a, b)                                        \
   if (t[b] < t[a]) {                                            \
@@ -354,6 +357,7 @@ __device__ __forceinline__ void trav_round(Trav &T, const SceneDev &S, const Sta
     else if (sp == 0) cur = MIPT_TRAV_DONE;
     else cur = (int)stack_pop(S, stk, sp);
     // few lanes left descending: let them pause so the others can go on with their leaves
+    constexpr int kMinDescending = ANY ? MIPT_MIN_DESC_ANY : MIPT_MIN_DESC_CLOSEST;
     if (kMinDescending > 0 && (int)__popcll(__ballot(cur >= 0)) < kMinDescending) break;
   }
   if (cur < 0 && cur != MIPT_TRAV_DONE) {

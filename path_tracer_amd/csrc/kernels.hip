@@ -175,7 +175,11 @@ __global__ void __launch_bounds__(kBlock) k_generate(SceneDev S, RenderConst rc,
 #ifndef MIPT_REFILL_IDLE
 #define MIPT_REFILL_IDLE 32
 #endif
-constexpr uint32_t kRefillIdle = MIPT_REFILL_IDLE;
+#ifndef MIPT_REFILL_IDLE_CLOSEST
+#define MIPT_REFILL_IDLE_CLOSEST MIPT_REFILL_IDLE
+#endif
+constexpr uint32_t kRefillIdle = MIPT_REFILL_IDLE;                  // shadow rays
+constexpr uint32_t kRefillIdleClosest = MIPT_REFILL_IDLE_CLOSEST;  // path rays
 
 __device__ __forceinline__ uint64_t wave_seq_item(uint32_t i, uint32_t wave, uint32_t n_waves) {
   return ((uint64_t)(i >> 6) * n_waves + wave) * 64ull + (i & 63u);
@@ -220,7 +224,7 @@ __global__ void __launch_bounds__(kBlock, MIPT_TRAV_WAVES) k_intersect(SceneDev 
       exhausted = wave_seq_item(next, wave, n_waves) >= n;
     }
     if (__ballot(!idle) == 0ull) break;
-    const uint32_t want_idle = exhausted ? 64u : kRefillIdle;
+    const uint32_t want_idle = exhausted ? 64u : kRefillIdleClosest;
     do {
       trav_round<false, COUNT>(T, S, stack, tc);
       if (!idle && T.cur == MIPT_TRAV_DONE) {

@@ -381,9 +381,19 @@ struct Collapser {
   int max_depth = 0;
   explicit Collapser(const std::vector<BinNode> &b) : bin(b) {}
 
-  // Emits the four-wide node that replaces binary node `n2` and returns its index; sets
-  // *need to the most stack entries a walk below it can hold at once.
+  // Emits the tree below binary node `n2`; returns the index of its root (always the first
+  // node emitted) and sets *need to the most stack entries a walk below it can hold at once.
   int32_t emit(int32_t n2, int depth, int *need) {
+    int32_t me = (int32_t)out.size();
+    out.emplace_back();
+    emit_into(me, n2, depth, need);
+    return me;
+  }
+
+  // Fills slot `me` with the four-wide node that replaces binary node `n2`.  The inner
+  // children of a node get adjacent slots (siblings are visited one after the other, so
+  // they share cache lines), each child's own children follow as it is filled.
+  void emit_into(int32_t me, int32_t n2, int depth, int *need) {
     Box6 boxes[4];
     int32_t refs[4];
     int n = 2;
@@ -407,19 +417,21 @@ struct Collapser {
         std::swap(boxes[j], boxes[j - 1]);
         std::swap(refs[j], refs[j - 1]);
       }
-    int32_t me = (int32_t)out.size();
-    out.emplace_back();
     max_depth = std::max(max_depth, depth + 1);
+    int32_t slot = (int32_t)out.size();
+    int inner = 0;
+    for (int k = 0; k < n; k++) inner += refs[k] >= 0 ? 1 : 0;
+    out.resize(out.size() + (size_t)inner);
     int below = 0;
     for (int k = 0; k < n; k++)
       if (refs[k] >= 0) {
         int nb = 0;
-        refs[k] = emit(refs[k], depth + 1, &nb);
+        emit_into(slot, refs[k], depth + 1, &nb);
+        refs[k] = slot++;
         below = std::max(below, nb);
       }
     quantise(out[(size_t)me], boxes, refs, n);
     *need = (n - 1) + below;
-    return me;
   }
 };
 
