@@ -172,6 +172,10 @@ def main():
 
     for s in range(W):
         ctx.render_accumulate(step_params(s, 0), d_sum.data_ptr(), stream)
+    if world > 1 and W > 0:
+        # the collective of the timed region, once, untimed: RCCL sets up its channels and
+        # buffers on first use
+        combine(d_sum.clone(), base, "samples", dst=0)
     ctx.reset_counters()
     sync()
     t0 = time.perf_counter()
