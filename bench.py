@@ -113,9 +113,9 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="synth1m", choices=sorted(list(WORKLOADS) + list(FIXTURE_WORKLOADS)))
-    ap.add_argument("--spp-per-step", type=int, default=32)
+    ap.add_argument("--spp-per-step", type=int, default=64)
     ap.add_argument("--triangles", type=int, default=0)
-    ap.add_argument("--batch-samples", type=int, default=1 << 26)
+    ap.add_argument("--batch-samples", type=int, default=1 << 27)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],

@@ -433,9 +433,9 @@ int mipt_render_accumulate(mipt_ctx *c, const mipt_params *p, double *d_sum, voi
   if ((r = ensure(c, c->accum, (size_t)batch * 3 * sizeof(double))) != MIPT_OK) return r;
   if ((r = ensure(c, c->rows, rows.size() * sizeof(int))) != MIPT_OK) return r;
   if ((r = ensure(c, c->counts, sizeof(BatchCounts))) != MIPT_OK) return r;
-  // visibility scratch: all shadow rays of a level if they fit 2^30 rays, else chunks of whole hits
+  // visibility scratch: all shadow rays of a level if they fit 2^31 rays, else chunks of whole hits
   uint64_t rays_per_hit = (uint64_t)std::max(1, c->dev.rays_per_hit);
-  uint64_t vis_rays = std::max<uint64_t>(std::min<uint64_t>((uint64_t)cap * rays_per_hit, 1ull << 30), rays_per_hit);
+  uint64_t vis_rays = std::max<uint64_t>(std::min<uint64_t>((uint64_t)cap * rays_per_hit, 1ull << 31), rays_per_hit);
   const uint64_t hits_per_chunk = std::min<uint64_t>(vis_rays / rays_per_hit, 0xffffff00ull / rays_per_hit);
   if ((r = ensure(c, c->vis, vis_rays * sizeof(double) * (c->dev.translucent ? 3 : 1))) != MIPT_OK) return r;
   if (!c->dcount.p) {
