@@ -57,6 +57,12 @@ typedef struct mipt_material {
   double roughness;
   double metallic;
   double index;
+  /* Texture-mapped parameters ({"mapped": file}, JsonParser.cpp:86-111;
+   * MaterialParameter::value, material.cpp:224-230): 0 = the constant above,
+   * k > 0 = mipt_scene_desc.textures[k - 1] looked up at the hit's UV
+   * coordinates (TextureMap::getMappedValue, material.cpp:186-222). */
+  int32_t kd_texture;
+  int32_t ka_texture;
 } mipt_material;
 
 /* One Geometry added to the Scene (scene/scene.cpp:103-107), in file order.
@@ -75,13 +81,18 @@ typedef struct mipt_object {
  * already triangulated (quads split as JsonParser.cpp:253-257 does);
  * degenerate faces are dropped by the library exactly as Trimesh::addFace does
  * (trimesh.cpp:32-46, trimesh.h:139-141).  normals is NULL or one vector per
- * vertex (interpolated as trimesh.cpp:154-163). */
+ * vertex (interpolated as trimesh.cpp:154-163); uvs is NULL or one (u, v) per
+ * vertex (the "UV" key, JsonParser.cpp:271-279; interpolated as
+ * trimesh.cpp:165-172).  Hits on a mesh without uvs, and on spheres, have UV
+ * (0, 0) (ray.h:71); squares and boxes set their own (Square.cpp:41,
+ * Box.cpp:62-71). */
 typedef struct mipt_mesh {
   const double *vertices; /* 3 * n_vertices */
   int64_t n_vertices;
   const int32_t *faces; /* 3 * n_faces   */
   int64_t n_faces;
   const double *normals; /* NULL or 3 * n_vertices */
+  const double *uvs;     /* NULL or 2 * n_vertices */
 } mipt_mesh;
 
 /* A light, fields as the JSON parser hands them to the constructors
@@ -109,9 +120,9 @@ typedef struct mipt_camera {
   double v[3];
 } mipt_camera;
 
-/* One cubemap face: 8-bit RGB, row 0 = bottom row, as readImage returns it
- * (fileio/pngimage.cpp:210-221).  Face order is CubeMap::tMap's
- * (scene/cubeMap.cpp:7-64): +x, -x, +y, -y, +z, -z. */
+/* One image (cubemap face or material texture): 8-bit RGB, row 0 = bottom row,
+ * as readImage returns it (fileio/pngimage.cpp:210-221).  Cubemap face order is
+ * CubeMap::tMap's (scene/cubeMap.cpp:7-64): +x, -x, +y, -y, +z, -z. */
 typedef struct mipt_image {
   const uint8_t *rgb; /* 3 * width * height */
   int32_t width;
@@ -130,6 +141,8 @@ typedef struct mipt_scene_desc {
   const mipt_light *lights;
   int32_t n_lights;
   const mipt_image *cubemap; /* NULL, or 6 faces (TraceUI::getCubeMap()) */
+  const mipt_image *textures; /* material textures (Scene::getTexture, scene.cpp:140-147) */
+  int32_t n_textures;
 } mipt_scene_desc;
 
 /* ---- render parameters ----------------------------------------------------- */
@@ -262,6 +275,14 @@ int mipt_trace_pixel(mipt_ctx *ctx, const mipt_params *p, int i, int j, double o
  * Test hook: the reference has no such call but every parity test needs it. */
 int mipt_intersect(mipt_ctx *ctx, int64_t n, const double *org, const double *dir, double t_max,
                    double *t, int32_t *prim, double *normal);
+
+/* What the closest hit of each ray hands to shadeBRDF as surface colours: out
+ * uv[2n] = isect::getUVCoordinates() (Square.cpp:41, Box.cpp:62-71,
+ * trimesh.cpp:165-172; (0, 0) elsewhere), kd[3n] and ka[3n] = Material::kd(i),
+ * ka(i) (material.h:197-212 through MaterialParameter::value,
+ * material.cpp:224-230).  Zeros on a miss.  Test hook. */
+int mipt_hit_material(mipt_ctx *ctx, int64_t n, const double *org, const double *dir, double t_max,
+                      double *uv, double *kd, double *ka);
 
 /* Light::shadowAttenuation * nothing else (light.cpp:15-35,63-85,114-147) for n
  * shading points: fire[3n] is firePos (material.cpp:117); the ray direction is

@@ -48,6 +48,8 @@ def load():
         fn = getattr(lib, name)
         fn.restype = C.c_int
         fn.argtypes = [vp, i64, vp, vp, dbl, vp, vp, vp]
+    lib.orc_hit_material.restype = C.c_int
+    lib.orc_hit_material.argtypes = [vp, i64, vp, vp, dbl, vp, vp, vp]
     lib.orc_shadow_attenuation.restype = C.c_int
     lib.orc_shadow_attenuation.argtypes = [vp, C.POINTER(abi.Params), C.c_int, i64, vp, vp, vp]
     lib.orc_shade_brdf.restype = C.c_int
@@ -128,6 +130,19 @@ class Oracle:
         if rc != 0:
             raise RuntimeError(f"orc_intersect rc={rc}")
         return t, prim, nrm
+
+    def hit_material(self, org, dir, t_max=1000.0):
+        """(uv, kd, ka) at the closest hit of every ray; zeros on a miss."""
+        org = np.ascontiguousarray(org, dtype=np.float64).reshape(-1, 3)
+        dir = np.ascontiguousarray(dir, dtype=np.float64).reshape(-1, 3)
+        n = org.shape[0]
+        uv = np.empty((n, 2), dtype=np.float64)
+        kd = np.empty((n, 3), dtype=np.float64)
+        ka = np.empty((n, 3), dtype=np.float64)
+        rc = self.lib.orc_hit_material(self._h, n, org.ctypes.data, dir.ctypes.data, t_max, uv.ctypes.data, kd.ctypes.data, ka.ctypes.data)
+        if rc != 0:
+            raise RuntimeError(f"orc_hit_material rc={rc}")
+        return uv, kd, ka
 
     def shadow_attenuation(self, params, light, fire, keys=None):
         fire = np.ascontiguousarray(fire, dtype=np.float64).reshape(-1, 3)

@@ -215,6 +215,7 @@ struct BBox {
 struct Material {
   V3 kd, ka, kt;
   double rough_raw, metal_raw, index_raw;
+  int kdTex = 0, kaTex = 0;  // 0 = constant, k > 0 = textures[k - 1] (MaterialParameter, material.h:76-120)
   // MaterialParameter::intensityValue, material.cpp:232-241: scalars are stored as
   // (v,v,v) and read back through luminance weights.
   static double intensity(double v) { return (0.299 * v) + (0.587 * v) + (0.114 * v); }
@@ -229,6 +230,7 @@ struct Isect {  // ray.h:67-145 (fields used on this path)
   int obj = -1;   // object index (file order) or -1 == NULL
   int prim = -1;  // reference-order primitive index
   int mat = -1;
+  double u = 0.0, v = 0.0;  // uvCoordinates, default-constructed to (0, 0) (ray.h:71)
 };
 
 struct Counters {
@@ -303,6 +305,7 @@ struct BVH {
 
 struct Mesh {
   std::vector<V3> verts, normals;
+  std::vector<double> uvs;  // 2 per vertex, or empty
   struct Face {
     int ids[3];
     V3 normal;
@@ -360,7 +363,17 @@ struct orc_scene {
   BVH tree;  // BVH<Geometry>
   bool hasCube = false;
   Tex cube[6];
+  std::vector<Tex> textures;
   int64_t nPrims = 0;
+
+  // MaterialParameter::value (material.cpp:224-230) for the two colours shadeBRDF reads
+  // through a texture: the material as the hit sees it.
+  Material materialAt(const Isect &i) const {
+    Material m = materials[i.mat];
+    if (m.kdTex > 0) m.kd = textures[(size_t)m.kdTex - 1].mapped(i.u, i.v);
+    if (m.kaTex > 0) m.ka = textures[(size_t)m.kaTex - 1].mapped(i.u, i.v);
+    return m;
+  }
 
   // ---- primitives ----------------------------------------------------------
   // Sphere.cpp:9-40
@@ -405,10 +418,17 @@ struct orc_scene {
     }
     if (bestIndex < 0) return false;
     i.t = bestT;
-    if (bestIndex < 3)
+    V3 ip = r.at(bestT);  // Box.cpp:56-71
+    int i1 = (bestIndex + 1) % 3, i2 = (bestIndex + 2) % 3;
+    if (bestIndex < 3) {
       i.N = V3(-double(bestIndex == 0), -double(bestIndex == 1), -double(bestIndex == 2));
-    else
+      i.u = 0.5 - ip[std::min(i1, i2)];
+      i.v = 0.5 + ip[std::max(i1, i2)];
+    } else {
       i.N = V3(double(bestIndex == 3), double(bestIndex == 4), double(bestIndex == 5));
+      i.u = 0.5 + ip[std::min(i1, i2)];
+      i.v = 0.5 + ip[std::max(i1, i2)];
+    }
     return true;
   }
   // Square.cpp:8-43
@@ -422,6 +442,8 @@ struct orc_scene {
     if (P.y < -0.5 || P.y > 0.5) return false;
     i.t = t;
     i.N = d.z > 0.0 ? V3(0.0, 0.0, -1.0) : V3(0.0, 0.0, 1.0);
+    i.u = P.x + 0.5;  // Square.cpp:41
+    i.v = P.y + 0.5;
     return true;
   }
   // trimesh.cpp:98-200
@@ -449,6 +471,13 @@ struct orc_scene {
     } else {
       i.N = normal;
     }
+    if (!m.uvs.empty()) {  // trimesh.cpp:165-172
+      double uA = m.uvs[2 * (size_t)f.ids[0]] * w0, vA = m.uvs[2 * (size_t)f.ids[0] + 1] * w0;
+      double uB = m.uvs[2 * (size_t)f.ids[1]] * w1, vB = m.uvs[2 * (size_t)f.ids[1] + 1] * w1;
+      double uC = m.uvs[2 * (size_t)f.ids[2]] * w2, vC = m.uvs[2 * (size_t)f.ids[2] + 1] * w2;
+      i.u = (uA + uB) + uC;
+      i.v = (vA + vB) + vC;
+    }
     i.t = t;
     return true;
   }
@@ -467,6 +496,8 @@ struct orc_scene {
         if (check && test.t < i.t) {
           i.t = test.t;
           i.N = test.N;
+          i.u = test.u;
+          i.v = test.v;
           i.prim = objPrimBase + nd.first + j;
         }
         hitAny |= check;
@@ -569,6 +600,8 @@ struct orc_scene {
             if (faceLocal(m, m.faces[m.tree.order[fi]], rl, ft) && ft.t < test.t) {
               test.t = ft.t;
               test.N = ft.N;
+              test.u = ft.u;
+              test.v = ft.v;
               test.prim = o.primBase + (int)fi;
             }
           }
@@ -764,7 +797,7 @@ struct orc_scene {
     Isect i;
     c.path_rays++;
     if (intersect(r, i, prm.t_max, c)) {
-      const Material &m = materials[i.mat];
+      const Material m = materialAt(i);
       double russianRoulette = rng.draw(key, SLOT_RR);
       if (russianRoulette < prm.rr_q) return V3(0);
       c.shaded++;
@@ -879,7 +912,17 @@ orc_scene *orc_create(const mipt_scene_desc *d) {
     mm.rough_raw = m.roughness;
     mm.metal_raw = m.metallic;
     mm.index_raw = m.index;
+    mm.kdTex = m.kd_texture;
+    mm.kaTex = m.ka_texture;
+    if (mm.kdTex < 0 || mm.kdTex > d->n_textures || mm.kaTex < 0 || mm.kaTex > d->n_textures) { g_err = "material texture index out of range"; return nullptr; }
     s->materials.push_back(mm);
+  }
+  for (int k = 0; k < d->n_textures; k++) {
+    Tex t;
+    t.w = d->textures[k].width;
+    t.h = d->textures[k].height;
+    t.data.assign(d->textures[k].rgb, d->textures[k].rgb + (size_t)3 * t.w * t.h);
+    s->textures.push_back(std::move(t));
   }
   for (int k = 0; k < d->n_meshes; k++) {
     const mipt_mesh &src = d->meshes[k];
@@ -890,6 +933,7 @@ orc_scene *orc_create(const mipt_scene_desc *d) {
       m.normals.resize((size_t)src.n_vertices);
       for (int64_t v = 0; v < src.n_vertices; v++) m.normals[v] = V3(src.normals[3 * v], src.normals[3 * v + 1], src.normals[3 * v + 2]);
     }
+    if (src.uvs) m.uvs.assign(src.uvs, src.uvs + 2 * (size_t)src.n_vertices);
     std::vector<BBox> fboxes;
     for (int64_t f = 0; f < src.n_faces; f++) {
       int a = src.faces[3 * f], b = src.faces[3 * f + 1], c = src.faces[3 * f + 2];
@@ -1099,6 +1143,29 @@ int orc_intersect(orc_scene *s, int64_t n, const double *org, const double *dir,
 }
 int orc_intersect_brute(orc_scene *s, int64_t n, const double *org, const double *dir, double tmax, double *t, int32_t *prim, double *normal) {
   return intersect_many(s, true, n, org, dir, tmax, t, prim, normal);
+}
+
+int orc_hit_material(orc_scene *s, int64_t n, const double *org, const double *dir, double tmax, double *uv, double *kd, double *ka) {
+  if (!s || !org || !dir || !uv || !kd || !ka) { g_err = "null argument"; return -1; }
+  for (int64_t k = 0; k < n; k++) {
+    Ray r;
+    r.p = V3(org[3 * k], org[3 * k + 1], org[3 * k + 2]);
+    r.d = V3(dir[3 * k], dir[3 * k + 1], dir[3 * k + 2]);
+    Isect i;
+    Counters c;
+    V3 d(0), a(0);
+    double u = 0, v = 0;
+    if (s->intersect(r, i, tmax, c)) {
+      Material m = s->materialAt(i);
+      d = m.kd;
+      a = m.ka;
+      u = i.u;
+      v = i.v;
+    }
+    uv[2 * k] = u; uv[2 * k + 1] = v;
+    for (int q = 0; q < 3; q++) { kd[3 * k + q] = d[q]; ka[3 * k + q] = a[q]; }
+  }
+  return 0;
 }
 
 int orc_shadow_attenuation(orc_scene *s, const mipt_params *p, int light, int64_t n, const double *fire, const uint64_t *key, double *out) {

@@ -56,6 +56,12 @@ int orc_trace_pixel(orc_scene *s, const mipt_params *p, int i, int j, double out
 int orc_intersect(orc_scene *s, int64_t n, const double *org, const double *dir, double t_max,
                   double *t, int32_t *prim, double *normal);
 
+/* What the closest hit of each ray hands to shadeBRDF: its UV coordinates (Square.cpp:41,
+ * Box.cpp:62-71, trimesh.cpp:165-172; (0, 0) elsewhere) and the diffuse and ambient colours
+ * as MaterialParameter::value returns them there (material.cpp:224-230).  Zeros on a miss. */
+int orc_hit_material(orc_scene *s, int64_t n, const double *org, const double *dir, double t_max,
+                     double *uv, double *kd, double *ka);
+
 /* The same closest hit found by testing every primitive with no BVH at all
  * (the commented-out loops of scene.cpp:115-128 / trimesh.cpp:72-84). */
 int orc_intersect_brute(orc_scene *s, int64_t n, const double *org, const double *dir,

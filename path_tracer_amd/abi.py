@@ -30,6 +30,8 @@ class Material(C.Structure):
         ("roughness", C.c_double),
         ("metallic", C.c_double),
         ("index", C.c_double),
+        ("kd_texture", C.c_int32),
+        ("ka_texture", C.c_int32),
     ]
 
 
@@ -50,6 +52,7 @@ class Mesh(C.Structure):
         ("faces", C.POINTER(C.c_int32)),
         ("n_faces", C.c_int64),
         ("normals", C.POINTER(C.c_double)),
+        ("uvs", C.POINTER(C.c_double)),
     ]
 
 
@@ -90,6 +93,8 @@ class SceneDesc(C.Structure):
         ("lights", C.POINTER(Light)),
         ("n_lights", C.c_int32),
         ("cubemap", C.POINTER(Image)),
+        ("textures", C.POINTER(Image)),
+        ("n_textures", C.c_int32),
     ]
 
 
@@ -184,6 +189,7 @@ SIGNATURES = {
     "mipt_render_accumulate": (C.c_int, [C.c_void_p, C.POINTER(Params), C.c_void_p, C.c_void_p]),
     "mipt_resolve": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mipt_trace_pixel": (C.c_int, [C.c_void_p, C.POINTER(Params), C.c_int, C.c_int, C.POINTER(C.c_double)]),
+    "mipt_hit_material": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mipt_intersect": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mipt_shadow_attenuation": (C.c_int, [C.c_void_p, C.POINTER(Params), C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mipt_get_counters": (C.c_int, [C.c_void_p, C.POINTER(Counters)]),

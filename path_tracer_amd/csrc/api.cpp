@@ -339,6 +339,19 @@ int mipt_upload_scene(mipt_ctx *c, const mipt_scene_desc *desc) {
   if (!H.tri_normals.empty()) {
     if ((r = upload(c, H.tri_normals, &D.tri_normals)) != MIPT_OK) return r;
   }
+  if (!H.tri_uvs.empty()) {
+    if ((r = upload(c, H.tri_uvs, &D.tri_uvs)) != MIPT_OK) return r;
+  }
+  if (!H.tex_rgb.empty()) {
+    std::vector<TexRec> table;
+    for (size_t k = 0; k < H.tex_rgb.size(); k++) {
+      const uint8_t *p = nullptr;
+      if ((r = upload(c, H.tex_rgb[k], &p)) != MIPT_OK) return r;
+      table.push_back(TexRec{p, H.tex_w[k], H.tex_h[k]});
+    }
+    if ((r = upload(c, table, &D.textures)) != MIPT_OK) return r;
+    D.n_textures = (int)table.size();
+  }
   if ((r = upload(c, H.prim_info, &D.prim_info)) != MIPT_OK) return r;
   if ((r = upload(c, H.ref_order, &D.ref_order)) != MIPT_OK) return r;
   if ((r = upload(c, H.objects, &D.objects)) != MIPT_OK) return r;
@@ -390,6 +403,8 @@ int mipt_upload_scene(mipt_ctx *c, const mipt_scene_desc *desc) {
   std::vector<Node4>().swap(H.nodes);
   std::vector<Tri>().swap(H.tris);
   std::vector<TriNormals>().swap(H.tri_normals);
+  std::vector<TriUV>().swap(H.tri_uvs);
+  std::vector<std::vector<uint8_t>>().swap(H.tex_rgb);
   std::vector<uint32_t>().swap(H.prim_info);
   std::vector<uint32_t>().swap(H.ref_order);
   for (int f = 0; f < 6; f++) std::vector<uint8_t>().swap(H.cube_rgb[f]);
@@ -637,6 +652,33 @@ int mipt_intersect(mipt_ctx *c, int64_t n, const double *org, const double *dir,
   if (e == hipSuccess) e = hipMemcpy(normal, d_n, v3, hipMemcpyDeviceToHost);
   (void)hipFree(d_org); (void)hipFree(d_dir); (void)hipFree(d_n); (void)hipFree(d_t); (void)hipFree(d_p);
   if (e != hipSuccess) return set_err(c, MIPT_ERR_DEVICE, "mipt_intersect: %s", hipGetErrorString(e));
+  return MIPT_OK;
+}
+
+int mipt_hit_material(mipt_ctx *c, int64_t n, const double *org, const double *dir, double t_max, double *uv, double *kd, double *ka) {
+  if (!c) return set_err(nullptr, MIPT_ERR_INVALID, "null context");
+  if (!c->have_scene) return set_err(c, MIPT_ERR_NOSCENE, "no scene uploaded");
+  if (n < 0 || (n > 0 && (!org || !dir || !uv || !kd || !ka))) return set_err(c, MIPT_ERR_INVALID, "bad arguments");
+  if (n == 0) return MIPT_OK;
+  HIP_TRY(c, hipSetDevice(c->device));
+  double *d_org = nullptr, *d_dir = nullptr, *d_uv = nullptr, *d_kd = nullptr, *d_ka = nullptr;
+  size_t v3 = (size_t)n * 3 * sizeof(double), v2 = (size_t)n * 2 * sizeof(double);
+  hipError_t e = hipMalloc((void **)&d_org, v3);
+  if (e == hipSuccess) e = hipMalloc((void **)&d_dir, v3);
+  if (e == hipSuccess) e = hipMalloc((void **)&d_kd, v3);
+  if (e == hipSuccess) e = hipMalloc((void **)&d_ka, v3);
+  if (e == hipSuccess) e = hipMalloc((void **)&d_uv, v2);
+  if (e == hipSuccess) e = hipMemcpy(d_org, org, v3, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(d_dir, dir, v3, hipMemcpyHostToDevice);
+  if (e == hipSuccess) {
+    launch_hit_material(c->dev, n, d_org, d_dir, t_max, d_uv, d_kd, d_ka, nullptr);
+    e = hipDeviceSynchronize();
+  }
+  if (e == hipSuccess) e = hipMemcpy(uv, d_uv, v2, hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemcpy(kd, d_kd, v3, hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemcpy(ka, d_ka, v3, hipMemcpyDeviceToHost);
+  (void)hipFree(d_org); (void)hipFree(d_dir); (void)hipFree(d_uv); (void)hipFree(d_kd); (void)hipFree(d_ka);
+  if (e != hipSuccess) return set_err(c, MIPT_ERR_DEVICE, "mipt_hit_material: %s", hipGetErrorString(e));
   return MIPT_OK;
 }
 

@@ -23,6 +23,9 @@ struct SceneDev {
   const Node4 *nodes;
   const Tri *tris;
   const TriNormals *tri_normals;  // may be null
+  const TriUV *tri_uvs;           // may be null
+  const TexRec *textures;         // material textures, n_textures of them
+  int n_textures;
   const uint32_t *prim_info;
   const uint32_t *ref_order;
   const ObjRec *objects;
@@ -66,7 +69,7 @@ __device__ __forceinline__ bool sphere_local(d3 p, d3 d, double &t, d3 &N) {
 }
 
 // Box::intersectLocal, Box.cpp:11-74.
-__device__ __forceinline__ bool box_local(d3 p, d3 d, double &t, d3 &N) {
+__device__ __forceinline__ bool box_local(d3 p, d3 d, double &t, d3 &N, int *face = nullptr) {
   double bestT = 1e100;
   int bestIndex = -1;
 #pragma unroll
@@ -88,6 +91,7 @@ __device__ __forceinline__ bool box_local(d3 p, d3 d, double &t, d3 &N) {
   }
   if (bestIndex < 0) return false;
   t = bestT;
+  if (face) *face = bestIndex;
   double s = bestIndex < 3 ? -1.0 : 1.0;
   int ax = bestIndex % 3;
   // the reference writes -double(bestIndex == k): the untouched components are -0.0
@@ -411,6 +415,45 @@ __device__ __forceinline__ d3 hit_normal(const SceneDev &S, int prim, d3 org, d3
   d3 Nl = d3{0, 0, 1};
   analytic_hit(o, kind, org, dir, t, Nl);
   return normalize(mul3(o->normi, Nl));
+}
+
+// UV coordinates of a hit, as isect::getUVCoordinates() holds them: Square.cpp:41,
+// Box.cpp:56-71, trimesh.cpp:165-172; (0, 0) for spheres and meshes without UVs (ray.h:71).
+__device__ __forceinline__ void hit_uv(const SceneDev &S, int prim, d3 org, d3 dir, double &u, double &v) {
+  u = 0.0;
+  v = 0.0;
+  uint32_t info = S.prim_info[prim];
+  uint32_t kind = info >> 30;
+  const ObjRec *o = S.objects + (info & 0x3fffffffu);
+  if (kind == KIND_TRI) {
+    double t, w1, w2;
+    if (o->has_uv && S.tri_uvs && tri_hit(S.tris + prim, org, dir, t, w1, w2)) {
+      const TriUV *q = S.tri_uvs + prim;
+      double w0 = 1 - w1 - w2;
+      u = (q->ua * w0 + q->ub * w1) + q->uc * w2;
+      v = (q->va * w0 + q->vb * w1) + q->vc * w2;
+    }
+    return;
+  }
+  if (kind == KIND_SPHERE) return;
+  d3 p = xform_point(o->inv, org);
+  d3 dl = normalize(xform_point(o->inv, org + dir) - p);
+  double tl;
+  d3 Nl;
+  if (kind == KIND_SQUARE) {
+    if (!square_local(p, dl, tl, Nl)) return;
+    d3 P = p + tl * dl;
+    u = P.x + 0.5;
+    v = P.y + 0.5;
+  } else {
+    int face = 0;
+    if (!box_local(p, dl, tl, Nl, &face)) return;
+    d3 P = p + tl * dl;
+    int i1 = (face + 1) % 3, i2 = (face + 2) % 3;
+    double lo = comp(P, i1 < i2 ? i1 : i2), hi = comp(P, i1 < i2 ? i2 : i1);
+    u = face < 3 ? 0.5 - lo : 0.5 + lo;
+    v = 0.5 + hi;
+  }
 }
 
 }  // namespace mipt

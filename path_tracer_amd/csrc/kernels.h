@@ -77,6 +77,8 @@ void launch_finalize(const double *d_sum, int64_t n_pixels, int spp, float *rgb_
 // Test hooks.
 void launch_intersect_rays(const SceneDev &S, int64_t n, const double *org, const double *dir, double t_max,
                            double *t, int *prim, double *normal, hipStream_t st);
+void launch_hit_material(const SceneDev &S, int64_t n, const double *org, const double *dir, double t_max, double *uv, double *kd,
+                         double *ka, hipStream_t st);
 void launch_shadow_attenuation(const SceneDev &S, const RenderConst &rc, int light, int64_t n, const double *fire,
                                const uint64_t *key, double *out, hipStream_t st);
 

@@ -278,7 +278,14 @@ __global__ void __launch_bounds__(kShadeBlock) k_shade(SceneDev S, RenderConst r
         P = o + t * d;  // r.at(i)
         const ObjRec *ob = S.objects + (S.prim_info[prim] & 0x3fffffffu);
         const MatRec *m = S.materials + ob->material;
-        d3 kd = ld3(m->kd);
+        d3 kd = ld3(m->kd), ka = ld3(m->ka);
+        if (S.n_textures > 0 && (m->kd_tex | m->ka_tex) != 0) {
+          // texture-mapped colours: MaterialParameter::value at the hit's UV, material.cpp:224-230
+          double tu, tv;
+          hit_uv(S, prim, o, d, tu, tv);
+          if (m->kd_tex > 0) { const TexRec &tx = S.textures[m->kd_tex - 1]; kd = tex_mapped(tx.data, tx.w, tx.h, tu, tv); }
+          if (m->ka_tex > 0) { const TexRec &tx = S.textures[m->ka_tex - 1]; ka = tex_mapped(tx.data, tx.w, tx.h, tu, tv); }
+        }
         // tangent frame, RayTracer.cpp:236-241
         d3 Nt;
         if (fabs(N.x) > fabs(N.y)) Nt = d3{N.z, 0, -N.x} / sqrt(N.x * N.x + N.z * N.z);
@@ -311,7 +318,7 @@ __global__ void __launch_bounds__(kShadeBlock) k_shade(SceneDev S, RenderConst r
         bool mirror = roughness < u3;
         double norm = (1.0 - rc.rr_q) * (mirror ? 2.0 : 1.0);
         // terms that need no shadow ray: ambient + direct specular, material.cpp:96,132-143
-        d3 A = ld3(m->ka) * ld3(S.ambient);
+        d3 A = ka * ld3(S.ambient);
         for (int li = 0; li < S.n_lights; li++) {
           const LightRec &L = S.lights[li];
           d3 Ld = light_direction(L, P);
@@ -667,6 +674,32 @@ __global__ void __launch_bounds__(kBlock) k_intersect_rays(SceneDev S, int64_t n
   }
 }
 
+__global__ void __launch_bounds__(kBlock) k_hit_material(SceneDev S, int64_t n, const double *__restrict__ org, const double *__restrict__ dir,
+                                                          double t_max, double *uv, double *kd_out, double *ka_out) {
+  extern __shared__ uint32_t lds_stack[];
+  const Stack stack{lds_stack + threadIdx.x, kBlock, blockIdx.x * kBlock + threadIdx.x};
+  TravCounters tc{0, 0};
+  for (int64_t idx = stack.gtid; idx < n; idx += (int64_t)gridDim.x * kBlock) {
+    d3 o{org[3 * idx], org[3 * idx + 1], org[3 * idx + 2]};
+    d3 d{dir[3 * idx], dir[3 * idx + 1], dir[3 * idx + 2]};
+    Hit h = traverse<false, false>(S, o, d, t_max, stack, tc);
+    double u = 0, v = 0;
+    d3 kd{0, 0, 0}, ka{0, 0, 0};
+    if (h.prim >= 0) {
+      const MatRec *m = S.materials + S.objects[S.prim_info[h.prim] & 0x3fffffffu].material;
+      kd = ld3(m->kd);
+      ka = ld3(m->ka);
+      hit_uv(S, h.prim, o, d, u, v);
+      if (m->kd_tex > 0) { const TexRec &tx = S.textures[m->kd_tex - 1]; kd = tex_mapped(tx.data, tx.w, tx.h, u, v); }
+      if (m->ka_tex > 0) { const TexRec &tx = S.textures[m->ka_tex - 1]; ka = tex_mapped(tx.data, tx.w, tx.h, u, v); }
+    }
+    uv[2 * idx] = u;
+    uv[2 * idx + 1] = v;
+    kd_out[3 * idx] = kd.x; kd_out[3 * idx + 1] = kd.y; kd_out[3 * idx + 2] = kd.z;
+    ka_out[3 * idx] = ka.x; ka_out[3 * idx + 1] = ka.y; ka_out[3 * idx + 2] = ka.z;
+  }
+}
+
 template <bool WALK>
 __global__ void __launch_bounds__(kBlock) k_shadow_attenuation(SceneDev S, RenderConst rc, int li, int64_t n, const double *__restrict__ fire,
                                                                 const uint64_t *__restrict__ key, double *out) {
@@ -789,6 +822,12 @@ void launch_intersect_rays(const SceneDev &S, int64_t n, const double *org, cons
                            double *normal, hipStream_t st) {
   if (!n) return;
   hipLaunchKernelGGL(k_intersect_rays, dim3(bounded_grid(S, (uint64_t)n)), dim3(kBlock), stack_bytes(S), st, S, n, org, dir, t_max, t, prim, normal);
+}
+
+void launch_hit_material(const SceneDev &S, int64_t n, const double *org, const double *dir, double t_max, double *uv, double *kd, double *ka,
+                         hipStream_t st) {
+  if (!n) return;
+  hipLaunchKernelGGL(k_hit_material, dim3(bounded_grid(S, (uint64_t)n)), dim3(kBlock), stack_bytes(S), st, S, n, org, dir, t_max, uv, kd, ka);
 }
 
 void launch_shadow_attenuation(const SceneDev &S, const RenderConst &rc, int light, int64_t n, const double *fire, const uint64_t *key,

@@ -53,6 +53,18 @@ struct alignas(8) TriNormals {
   double na[3], nb[3], nc[3];
 };
 
+// Per-vertex UV coordinates of one triangle (the mesh's "UV" key), in the order of the
+// barycentric weights: uv = (ua, va) * w0 + (ub, vb) * w1 + (uc, vc) * w2, trimesh.cpp:165-172.
+struct alignas(8) TriUV {
+  double ua, va, ub, vb, uc, vc;
+};
+
+// One material texture: 8-bit RGB, row 0 = bottom row.
+struct TexRec {
+  const uint8_t *data;
+  int32_t w, h;
+};
+
 // One scene object (file order).  inv = rows 0..2 of the inverse transform,
 // row-major 3x4 (MatrixTransform::globalToLocalCoords, scene.h:80-82); normi =
 // transpose(inverse(mat3(xform))), row-major 3x3 (scene.h:76,92-94).
@@ -62,7 +74,7 @@ struct alignas(8) ObjRec {
   int32_t kind;
   int32_t material;
   int32_t smooth;  // mesh has per-vertex normals
-  int32_t pad;
+  int32_t has_uv;  // mesh has per-vertex UV coordinates
 };
 
 // Material record as shadeBRDF reads it (material.cpp:88-109).  Scalars already
@@ -74,6 +86,7 @@ struct alignas(8) MatRec {
   double roughness;  // as the mirror test reads it (RayTracer.cpp:269)
   double metallic;
   double index;
+  int32_t kd_tex, ka_tex;  // 0 = the constant, k > 0 = texture k - 1 at the hit's UV (material.cpp:224-230)
 };
 
 struct alignas(8) LightRec {

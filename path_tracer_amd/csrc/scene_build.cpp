@@ -522,6 +522,10 @@ int build_host_scene(const mipt_scene_desc *d, HostScene *out, std::string *err)
     r.roughness = lum(m.roughness);
     r.metallic = lum(m.metallic);
     r.index = lum(m.index);
+    if (m.kd_texture < 0 || m.kd_texture > d->n_textures || m.ka_texture < 0 || m.ka_texture > d->n_textures)
+      return fail(MIPT_ERR_INVALID, "material texture index out of range");
+    r.kd_tex = m.kd_texture;
+    r.ka_tex = m.ka_texture;
     if (m.kt[0] != 0.0 || m.kt[1] != 0.0 || m.kt[2] != 0.0) S.translucent = true;
     S.materials.push_back(r);
   }
@@ -581,6 +585,7 @@ int build_host_scene(const mipt_scene_desc *d, HostScene *out, std::string *err)
       if (m.n_vertices < 0 || m.n_faces < 0 || (m.n_vertices && !m.vertices) || (m.n_faces && !m.faces))
         return fail(MIPT_ERR_INVALID, "bad mesh arrays");
       o.smooth = m.normals ? 1 : 0;
+      o.has_uv = m.uvs ? 1 : 0;
       if (m.n_vertices == 0) have = false;
       else {
         mn = mx = D3{m.vertices[0], m.vertices[1], m.vertices[2]};  // trimesh.h:75-90
@@ -613,9 +618,12 @@ int build_host_scene(const mipt_scene_desc *d, HostScene *out, std::string *err)
   std::vector<Tri> trisRef;          // by reference-order index
   std::vector<TriNormals> normsRef;  // by reference-order index (if any smooth mesh)
   std::vector<uint32_t> infoRef;
-  bool anySmooth = false;
-  for (size_t k = 0; k < nObj; k++)
+  std::vector<TriUV> uvsRef;         // by reference-order index (if any mesh has UV coordinates)
+  bool anySmooth = false, anyUV = false;
+  for (size_t k = 0; k < nObj; k++) {
     if (S.objects[k].smooth) anySmooth = true;
+    if (S.objects[k].has_uv) anyUV = true;
+  }
 
   for (size_t ord = 0; ord < nObj; ord++) {
     uint32_t oi = objOrder[ord];
@@ -634,6 +642,7 @@ int build_host_scene(const mipt_scene_desc *d, HostScene *out, std::string *err)
       std::memset(&t, 0, sizeof(t));
       trisRef.push_back(t);
       if (anySmooth) { TriNormals tn; std::memset(&tn, 0, sizeof(tn)); normsRef.push_back(tn); }
+      if (anyUV) uvsRef.push_back(TriUV{0, 0, 0, 0, 0, 0});
       infoRef.push_back(make_prim_info((uint32_t)src.type, oi));
       continue;
     }
@@ -667,6 +676,7 @@ int build_host_scene(const mipt_scene_desc *d, HostScene *out, std::string *err)
     prims.resize(base + nf);
     trisRef.resize(base + nf);
     if (anySmooth) normsRef.resize(base + nf);
+    if (anyUV) uvsRef.resize(base + nf);
     infoRef.resize(base + nf);
     auto do_faces = [&](size_t q0, size_t q1) {
     for (size_t q = q0; q < q1; q++) {
@@ -708,6 +718,11 @@ int build_host_scene(const mipt_scene_desc *d, HostScene *out, std::string *err)
           tn.nc[0] = nc.x; tn.nc[1] = nc.y; tn.nc[2] = nc.z;
         }
         normsRef[base + q] = tn;
+      }
+      if (anyUV) {
+        TriUV tu{0, 0, 0, 0, 0, 0};
+        if (m.uvs) tu = TriUV{m.uvs[2 * ia], m.uvs[2 * ia + 1], m.uvs[2 * ib], m.uvs[2 * ib + 1], m.uvs[2 * ic], m.uvs[2 * ic + 1]};
+        uvsRef[base + q] = tu;
       }
       infoRef[base + q] = make_prim_info(KIND_TRI, oi);
     }
@@ -784,12 +799,14 @@ int build_host_scene(const mipt_scene_desc *d, HostScene *out, std::string *err)
   S.prim_info.resize(nPrims);
   S.ref_order.resize(nPrims);
   if (anySmooth) S.tri_normals.resize(nPrims);
+  if (anyUV) S.tri_uvs.resize(nPrims);
   for (size_t s = 0; s < nPrims; s++) {
     uint32_t id = prims[s].id;
     S.tris[s] = trisRef[id];
     S.prim_info[s] = infoRef[id];
     S.ref_order[s] = id;
     if (anySmooth) S.tri_normals[s] = normsRef[id];
+    if (anyUV) S.tri_uvs[s] = uvsRef[id];
   }
   timer.lap("leaf-order arrays");
   double R = 0;
@@ -806,6 +823,14 @@ int build_host_scene(const mipt_scene_desc *d, HostScene *out, std::string *err)
       S.cube_h[f] = im.height;
       S.cube_rgb[f].assign(im.rgb, im.rgb + (size_t)3 * im.width * im.height);
     }
+  }
+  if (d->n_textures < 0 || (d->n_textures && !d->textures)) return fail(MIPT_ERR_INVALID, "bad texture array");
+  for (int k = 0; k < d->n_textures; k++) {
+    const mipt_image &im = d->textures[k];
+    if (im.width <= 0 || im.height <= 0 || !im.rgb) return fail(MIPT_ERR_INVALID, "bad texture image");
+    S.tex_w.push_back(im.width);
+    S.tex_h.push_back(im.height);
+    S.tex_rgb.emplace_back(im.rgb, im.rgb + (size_t)3 * im.width * im.height);
   }
   return MIPT_OK;
 }

@@ -17,6 +17,7 @@ struct HostScene {
   std::vector<Node4> nodes;            // nodes[0] is the root
   std::vector<Tri> tris;               // per primitive (leaf order); unused slots for analytic prims
   std::vector<TriNormals> tri_normals; // per primitive, empty if no mesh has vertex normals
+  std::vector<TriUV> tri_uvs;          // per primitive, empty if no mesh has UV coordinates
   std::vector<uint32_t> prim_info;     // kind << 30 | object
   int n_analytic = 0;                  // primitives [0, n_analytic) are spheres/boxes/squares, the rest triangles
   std::vector<uint32_t> ref_order;     // reference visiting order of each primitive (tie-break key)
@@ -31,6 +32,8 @@ struct HostScene {
   bool has_cubemap = false;
   int cube_w[6], cube_h[6];
   std::vector<uint8_t> cube_rgb[6];
+  std::vector<std::vector<uint8_t>> tex_rgb;  // material textures
+  std::vector<int> tex_w, tex_h;
 };
 
 // Returns MIPT_OK or an error code with `err` set.

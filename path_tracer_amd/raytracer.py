@@ -86,6 +86,17 @@ class Context:
         self._check(self.lib.mipt_intersect(self._h, n, org.ctypes.data, dir.ctypes.data, t_max, t.ctypes.data, prim.ctypes.data, nrm.ctypes.data))
         return t, prim, nrm
 
+    def hit_material(self, org, dir, t_max: float = 1000.0):
+        """(uv, kd, ka) at the closest hit of every ray; zeros on a miss."""
+        org = np.ascontiguousarray(org, dtype=np.float64).reshape(-1, 3)
+        dir = np.ascontiguousarray(dir, dtype=np.float64).reshape(-1, 3)
+        n = org.shape[0]
+        uv = np.empty((n, 2), dtype=np.float64)
+        kd = np.empty((n, 3), dtype=np.float64)
+        ka = np.empty((n, 3), dtype=np.float64)
+        self._check(self.lib.mipt_hit_material(self._h, n, org.ctypes.data, dir.ctypes.data, t_max, uv.ctypes.data, kd.ctypes.data, ka.ctypes.data))
+        return uv, kd, ka
+
     def shadow_attenuation(self, params: abi.Params, light: int, fire, keys=None):
         fire = np.ascontiguousarray(fire, dtype=np.float64).reshape(-1, 3)
         n = fire.shape[0]

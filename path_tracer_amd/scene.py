@@ -6,14 +6,19 @@ square / tri_mesh geometry (:179-311) and the transform stack (:59-67, :384-445)
 glm's rotate/scale/translate/make_mat4 semantics.  It produces the flat description
 `include/mipt.h` takes (`mipt_scene_desc`); no rendering happens here.
 
-Out of scope (raises): cylinder / cone (no path-tracer scene uses them), texture-mapped
-material parameters, obj_mesh.
+Texture-mapped material parameters ({"mapped": file}) are supported for the two colours
+shadeBRDF reads through a texture, diffuse and ambient; mapped specular / reflective /
+emissive / normal are parsed and dropped like the constants of those keys (shadeBRDF never
+reads them), a mapped transmissive is refused.
+
+Out of scope (raises): cylinder / cone (no path-tracer scene uses them), obj_mesh.
 """
 from __future__ import annotations
 
 import ctypes as C
 import json
 import math
+import os
 from dataclasses import dataclass, field
 from typing import List, Optional
 
@@ -32,9 +37,12 @@ class MaterialRec:
     roughness: float = 1.0  # material.h:152-158
     metallic: float = 0.0
     index: float = 1.0
+    kd_texture: int = 0  # 0 = constant, k > 0 = Scene.textures[k - 1]
+    ka_texture: int = 0
 
     def copy(self) -> "MaterialRec":
-        return MaterialRec(self.kd.copy(), self.ka.copy(), self.kt.copy(), self.roughness, self.metallic, self.index)
+        return MaterialRec(self.kd.copy(), self.ka.copy(), self.kt.copy(), self.roughness, self.metallic, self.index,
+                           self.kd_texture, self.ka_texture)
 
 
 @dataclass
@@ -50,6 +58,7 @@ class MeshRec:
     vertices: np.ndarray  # (n, 3) float64
     faces: np.ndarray  # (m, 3) int32
     normals: Optional[np.ndarray] = None  # (n, 3) float64
+    uvs: Optional[np.ndarray] = None  # (n, 2) float64
 
 
 @dataclass
@@ -110,6 +119,7 @@ class Scene:
     meshes: List[MeshRec] = field(default_factory=list)
     lights: List[LightRec] = field(default_factory=list)
     cubemap: Optional[List[np.ndarray]] = None  # six (h, w, 3) uint8, row 0 = bottom
+    textures: List[np.ndarray] = field(default_factory=list)  # (h, w, 3) uint8, row 0 = bottom
 
     # ------------------------------------------------------------------ C view
     def to_c(self):
@@ -126,6 +136,7 @@ class Scene:
             mats[k].ka = abi.c_double3(*map(float, m.ka))
             mats[k].kt = abi.c_double3(*map(float, m.kt))
             mats[k].roughness, mats[k].metallic, mats[k].index = float(m.roughness), float(m.metallic), float(m.index)
+            mats[k].kd_texture, mats[k].ka_texture = int(m.kd_texture), int(m.ka_texture)
         objs = (abi.Object * max(1, len(self.objects)))()
         for k, o in enumerate(self.objects):
             objs[k].type, objs[k].material, objs[k].mesh = int(o.type), int(o.material), int(o.mesh)
@@ -144,6 +155,10 @@ class Scene:
                 n = np.ascontiguousarray(m.normals, dtype=np.float64)
                 keep.append(n)
                 meshes[k].normals = n.ctypes.data_as(C.POINTER(C.c_double))
+            if m.uvs is not None:
+                uv = np.ascontiguousarray(m.uvs, dtype=np.float64)
+                keep.append(uv)
+                meshes[k].uvs = uv.ctypes.data_as(C.POINTER(C.c_double))
         lights = (abi.Light * max(1, len(self.lights)))()
         for k, L in enumerate(self.lights):
             lights[k].type = int(L.type)
@@ -165,6 +180,15 @@ class Scene:
                 faces[k].height, faces[k].width = img.shape[0], img.shape[1]
             d.cubemap = faces
             keep.append(faces)
+        if self.textures:
+            tex = (abi.Image * len(self.textures))()
+            for k, t in enumerate(self.textures):
+                img = np.ascontiguousarray(t, dtype=np.uint8)
+                keep.append(img)
+                tex[k].rgb = img.ctypes.data_as(C.POINTER(C.c_uint8))
+                tex[k].height, tex[k].width = img.shape[0], img.shape[1]
+            d.textures, d.n_textures = tex, len(self.textures)
+            keep.append(tex)
         return d, keep
 
     # ------------------------------------------------------------ npz fixtures
@@ -185,12 +209,17 @@ class Scene:
             ).reshape(len(self.lights), 17),
             "light_atten": np.array([L.atten for L in self.lights], dtype=np.float32).reshape(-1, 3),
             "n_meshes": np.array([len(self.meshes)], dtype=np.int32),
+            "material_textures": np.array([[m.kd_texture, m.ka_texture] for m in self.materials], dtype=np.int32).reshape(-1, 2),
         }
         for k, m in enumerate(self.meshes):
             arrs[f"mesh{k}_v"] = m.vertices
             arrs[f"mesh{k}_f"] = m.faces
             if m.normals is not None:
                 arrs[f"mesh{k}_n"] = m.normals
+            if m.uvs is not None:
+                arrs[f"mesh{k}_uv"] = m.uvs
+        for k, t in enumerate(self.textures):
+            arrs[f"texture{k}"] = t
         if self.cubemap is not None:
             for k in range(6):
                 arrs[f"cube{k}"] = self.cubemap[k]
@@ -203,15 +232,22 @@ class Scene:
         cam = z["camera"]
         s.camera.eye, s.camera.look, s.camera.u, s.camera.v = cam[0], cam[1], cam[2], cam[3]
         s.ambient = z["ambient"]
-        for row in z["materials"]:
-            s.materials.append(MaterialRec(row[0:3].copy(), row[3:6].copy(), row[6:9].copy(), float(row[9]), float(row[10]), float(row[11])))
+        mtex = z["material_textures"] if "material_textures" in z.files else np.zeros((len(z["materials"]), 2), dtype=np.int32)
+        for row, tx in zip(z["materials"], mtex):
+            s.materials.append(MaterialRec(row[0:3].copy(), row[3:6].copy(), row[6:9].copy(), float(row[9]), float(row[10]), float(row[11]),
+                                           int(tx[0]), int(tx[1])))
         for meta, xf in zip(z["obj_meta"], z["obj_xform"]):
             s.objects.append(ObjectRec(int(meta[0]), int(meta[1]), int(meta[2]), xf.copy()))
         for t, vec, att in zip(z["light_meta"], z["light_vec"], z["light_atten"]):
             s.lights.append(LightRec(int(t), vec[0:3].copy(), vec[3:6].copy(), vec[6:9].copy(), vec[9:12].copy(), vec[12:15].copy(), float(vec[15]), float(vec[16]), att.copy()))
         for k in range(int(z["n_meshes"][0])):
             n = z[f"mesh{k}_n"] if f"mesh{k}_n" in z.files else None
-            s.meshes.append(MeshRec(z[f"mesh{k}_v"], z[f"mesh{k}_f"], n))
+            uv = z[f"mesh{k}_uv"] if f"mesh{k}_uv" in z.files else None
+            s.meshes.append(MeshRec(z[f"mesh{k}_v"], z[f"mesh{k}_f"], n, uv))
+        k = 0
+        while f"texture{k}" in z.files:
+            s.textures.append(z[f"texture{k}"])
+            k += 1
         if "cube0" in z.files:
             s.cubemap = [z[f"cube{k}"] for k in range(6)]
         return s
@@ -265,11 +301,38 @@ def _vec3(j):
     return np.array([float(j[0]), float(j[1]), float(j[2])])
 
 
+def load_image(path: str) -> np.ndarray:
+    """readImage as TextureMap uses it (material.cpp:172-184, fileio/pngimage.cpp:199-221):
+    8-bit RGB, rows bottom-up.  Palette and grey images are expanded to RGB like libpng is
+    told to; images with an alpha channel are refused (the reference keeps four channels
+    and then indexes them as three, material.cpp:212-222: not reproduced), and so are files
+    whose gamma chunk would make libpng rescale the samples (gamma * 2.2 != 1)."""
+    from PIL import Image
+
+    im = Image.open(path)
+    g = im.info.get("gamma")
+    if g is not None and abs(float(g) * 2.2 - 1.0) > 0.011:  # libpng skips gamma within 0.05 / ...; 0.45455 * 2.2 = 1.00001
+        raise NotImplementedError(f"{path}: gamma {g} would be corrected by libpng, not supported")
+    if im.mode in ("RGBA", "LA", "PA") or "transparency" in im.info:
+        raise NotImplementedError(f"{path}: textures with an alpha channel are not supported")
+    a = np.asarray(im.convert("RGB"), dtype=np.uint8)
+    return np.ascontiguousarray(a[::-1])
+
+
 class _Parser:
-    def __init__(self):
+    def __init__(self, scene_dir: str = "."):
         self.scene = Scene()
         self.cur_mat = MaterialRec()
         self.stack: List[np.ndarray] = []
+        self.scene_dir = scene_dir
+        self.texture_cache = {}
+
+    def texture_index(self, name: str) -> int:  # Scene::getTexture, scene.cpp:140-147: one TextureMap per path
+        path = os.path.join(self.scene_dir, name)
+        if path not in self.texture_cache:
+            self.scene.textures.append(load_image(path))
+            self.texture_cache[path] = len(self.scene.textures)
+        return self.texture_cache[path]
 
     def current_transform(self):  # JsonParser.cpp:59-67
         m = np.eye(4)
@@ -292,15 +355,21 @@ class _Parser:
                 except (TypeError, ValueError):
                     return None
             if isinstance(p, dict) and "mapped" in p:
-                raise NotImplementedError("texture-mapped material parameters are out of scope")
+                return str(p["mapped"])
             raise SceneFormatError("Material parameter must be either constant or mapped")
 
         for key, attr in (("ambient", "ka"), ("diffuse", "kd"), ("transmissive", "kt")):
             v = param(key)
-            if v is not None:
+            if isinstance(v, str):
+                if attr == "kt":
+                    raise NotImplementedError("a texture-mapped transmissive colour is not supported")
+                setattr(m, attr + "_texture", self.texture_index(v))
+            elif v is not None:
                 setattr(m, attr, v)
+                if attr != "kt":
+                    setattr(m, attr + "_texture", 0)
         for key in ("specular", "reflective", "emissive", "normal"):
-            param(key)  # parsed by the reference, never read by shadeBRDF
+            param(key)  # parsed by the reference, never read by shadeBRDF (a mapped one would also load the file)
         for key, attr in (("index", "index"), ("metallic", "metallic"), ("roughness", "roughness")):
             if isinstance(j, dict) and isinstance(j.get(key), (int, float)) and not isinstance(j.get(key), bool):
                 setattr(m, attr, float(j[key]))
@@ -346,11 +415,18 @@ class _Parser:
             normals = np.array([[float(n[0]), float(n[1]), float(n[2])] for n in j["normals"]], dtype=np.float64).reshape(-1, 3)
             if len(normals) != len(verts):
                 raise SceneFormatError("Bad Trimesh: Wrong number of normals.")
+        uvs = None
+        if "UV" in j:  # JsonParser.cpp:271-279
+            uvs = np.array([[float(t[0]), float(t[1])] for t in j["UV"]], dtype=np.float64).reshape(-1, 2)
+            if len(uvs) == 0:
+                uvs = None
+            elif len(uvs) != len(verts):
+                raise SceneFormatError("Error in mesh: Bad Trimesh: Wrong number of UV coordinates.")
         if "materials" in j:
             raise SceneFormatError('"materials" key is no longer supported: use obj_mesh instead')
         if j.get("gennormals") is True:
             normals = generate_normals(verts, faces, normals)
-        self.scene.meshes.append(MeshRec(verts, faces, normals))
+        self.scene.meshes.append(MeshRec(verts, faces, normals, uvs))
         self.scene.objects.append(ObjectRec(abi.OBJ_TRIMESH, mat, len(self.scene.meshes) - 1, xf))
 
     def parse_transform(self, obj):  # JsonParser.cpp:384-445
@@ -448,8 +524,8 @@ def load_json_scene(path: str) -> Scene:
     """RayTracer::loadScene for a .json scene (RayTracer.cpp:333-415)."""
     with open(path, "r") as fh:
         j = json.load(fh)
-    return _Parser().parse_scene(j)
+    return _Parser(os.path.dirname(os.path.abspath(path))).parse_scene(j)
 
 
-def parse_json_scene(text: str) -> Scene:
-    return _Parser().parse_scene(json.loads(text))
+def parse_json_scene(text: str, scene_dir: str = ".") -> Scene:
+    return _Parser(scene_dir).parse_scene(json.loads(text))
