@@ -22,6 +22,7 @@ int main(int argc, char **argv) {
       for (int k = 0; k < 16; k++) std::printf(" %.17g", o.xform[k]);
       std::printf(" mat %.17g %.17g %.17g %.17g %.17g %.17g %.17g %.17g %.17g %.17g %.17g %.17g\n", m.kd[0], m.kd[1], m.kd[2], m.ka[0], m.ka[1],
                   m.ka[2], m.kt[0], m.kt[1], m.kt[2], m.roughness, m.metallic, m.index);
+      std::printf("mattex %d %d\n", m.kd_texture, m.ka_texture);
     }
     for (int i = 0; i < d.n_meshes; i++) {
       const mipt_mesh &m = d.meshes[i];
@@ -31,6 +32,17 @@ int main(int argc, char **argv) {
       if (m.normals)
         for (long long k = 0; k < 3 * m.n_vertices; k++) std::printf(" %.17g", m.normals[k]);
       std::printf("\n");
+      if (m.uvs) {
+        std::printf("uv");
+        for (long long k = 0; k < 2 * m.n_vertices; k++) std::printf(" %.17g", m.uvs[k]);
+        std::printf("\n");
+      }
+    }
+    for (int i = 0; i < d.n_textures; i++) {
+      const mipt_image &t = d.textures[i];
+      unsigned long long sum = 0;
+      for (long long k = 0; k < 3ll * t.width * t.height; k++) sum = sum * 31ull + t.rgb[k];
+      std::printf("texture %d %d %llu %d %d %d\n", t.width, t.height, sum, t.rgb[0], t.rgb[1], t.rgb[2]);
     }
     for (int i = 0; i < d.n_lights; i++) {
       const mipt_light &L = d.lights[i];

@@ -120,6 +120,21 @@ struct Parser {
   SceneData scene;
   mipt_material cur = default_material();
   std::vector<Mat4> stack;
+  std::string scene_dir = ".";
+
+  // Scene::getTexture, scene.cpp:140-147: one texture per path.  Returns index + 1.
+  int textureIndex(const std::string &name) {
+    std::string path = scene_dir + "/" + name;
+    for (size_t k = 0; k < scene.textures.size(); k++)
+      if (scene.textures[k].path == path) return (int)k + 1;
+    SceneData::Texture t;
+    t.path = path;
+    if (path.size() < 4 || path.compare(path.size() - 4, 4, ".ppm") != 0)
+      throw SceneError("Unable to load texture map '" + path + "': this host reads binary PPM textures only");
+    read_ppm(path, &t.w, &t.h, &t.rgb);
+    scene.textures.push_back(std::move(t));
+    return (int)scene.textures.size();
+  }
 
   Mat4 currentTransform() const {  // JsonParser.cpp:59-67
     Mat4 t = Mat4::identity();
@@ -129,31 +144,39 @@ struct Parser {
 
   // parseMaterialParameter, JsonParser.cpp:86-111.  Returns false when the key is absent
   // or ill-typed (IGNORE_MISSING leaves the value unchanged).
-  bool param(const Json &j, const char *key, double out[3]) {
+  // `texture`: where a {"mapped": file} parameter puts its texture (index + 1); null for the
+  // parameters shadeBRDF never reads (dropped) and for transmissive (refused).
+  bool param(const Json &j, const char *key, double out[3], int32_t *texture = nullptr, bool droppable = true) {
     if (!j.has(key)) return false;
     const Json &p = j.at(key);
     if (p.has("constant")) {
       try {
         Vec3 v = vec3(p.at("constant"));
         out[0] = v[0]; out[1] = v[1]; out[2] = v[2];
+        if (texture) *texture = 0;
         return true;
       } catch (const JsonError &) {
         return false;
       }
     }
-    if (p.has("mapped")) throw SceneError("texture-mapped material parameters are not supported by this host");
+    if (p.has("mapped")) {
+      if (texture) { *texture = textureIndex(p.at("mapped").str); return true; }
+      if (droppable) return false;
+      throw SceneError("a texture-mapped transmissive colour is not supported");
+    }
     throw SceneError("Material parameter must be either constant or mapped");
   }
 
   mipt_material parseMaterial(const Json &j) {  // JsonParser.cpp:113-131
     mipt_material m = cur;
     double tmp[3];
-    param(j, "ambient", m.ka);
-    param(j, "diffuse", m.kd);
+    param(j, "ambient", m.ka, &m.ka_texture);
+    param(j, "diffuse", m.kd, &m.kd_texture);
     param(j, "specular", tmp);
     param(j, "reflective", tmp);
-    param(j, "transmissive", m.kt);
+    param(j, "transmissive", m.kt, nullptr, false);
     param(j, "emissive", tmp);
+    param(j, "normal", tmp);
     if (j.has("index") && j.at("index").is_number()) m.index = j.at("index").number();
     if (j.has("metallic") && j.at("metallic").is_number()) m.metallic = j.at("metallic").number();
     if (j.has("roughness") && j.at("roughness").is_number()) m.roughness = j.at("roughness").number();
@@ -202,6 +225,14 @@ struct Parser {
         mesh.normals.insert(mesh.normals.end(), v.begin(), v.end());
       }
       if (mesh.normals.size() != mesh.vertices.size()) throw SceneError("Bad Trimesh: Wrong number of normals.");
+    }
+    if (j.has("UV")) {  // JsonParser.cpp:271-279
+      for (const Json &t : j.at("UV").arr) {
+        if (t.arr.size() < 2) throw SceneError("a UV coordinate needs two numbers");
+        mesh.uvs.push_back(t.arr[0].number());
+        mesh.uvs.push_back(t.arr[1].number());
+      }
+      if (!mesh.uvs.empty() && mesh.uvs.size() / 2 != nv) throw SceneError("Error in mesh: Bad Trimesh: Wrong number of UV coordinates.");
     }
     if (j.has("materials")) throw SceneError("\"materials\" key is no longer supported: use obj_mesh instead");
     bool gen = false;
@@ -338,9 +369,10 @@ struct Parser {
 
 }  // namespace
 
-SceneData parse_scene(const Json &root) {
+SceneData parse_scene(const Json &root, const std::string &scene_dir) {
   if (!root.is_array()) throw SceneError("a scene is a JSON array");
   Parser p;
+  p.scene_dir = scene_dir;
   p.parseScene(root);
   return std::move(p.scene);
 }
@@ -350,7 +382,8 @@ SceneData load_scene_file(const std::string &path) {
   if (!ifs) throw SceneError("Error: couldn't read scene file " + path);  // RayTracer.cpp:336-342
   std::stringstream ss;
   ss << ifs.rdbuf();
-  return parse_scene(Json::parse(ss.str()));
+  size_t slash = path.find_last_of('/');
+  return parse_scene(Json::parse(ss.str()), slash == std::string::npos ? "." : path.substr(0, slash));
 }
 
 mipt_scene_desc SceneData::describe() {
@@ -370,6 +403,7 @@ mipt_scene_desc SceneData::describe() {
     v.faces = m.faces.data();
     v.n_faces = (int64_t)(m.faces.size() / 3);
     v.normals = m.normals.empty() ? nullptr : m.normals.data();
+    v.uvs = m.uvs.empty() ? nullptr : m.uvs.data();
     mesh_views_.push_back(v);
   }
   d.meshes = mesh_views_.data();
@@ -385,27 +419,39 @@ mipt_scene_desc SceneData::describe() {
     }
     d.cubemap = cube_views_;
   }
+  texture_views_.clear();
+  for (const Texture &t : textures) texture_views_.push_back(mipt_image{t.rgb.data(), t.w, t.h});
+  d.textures = texture_views_.empty() ? nullptr : texture_views_.data();
+  d.n_textures = (int32_t)texture_views_.size();
   return d;
+}
+
+void read_ppm(const std::string &path, int *w, int *h, std::vector<uint8_t> *rgb) {
+  std::ifstream in(path, std::ios::binary);
+  if (!in) throw SceneError("Unable to load image '" + path + "'.");
+  std::string magic;
+  int maxv = 0;
+  in >> magic >> *w >> *h >> maxv;
+  in.get();
+  if (magic != "P6" || *w <= 0 || *h <= 0 || maxv != 255) throw SceneError("unsupported PPM: " + path);
+  std::vector<uint8_t> top((size_t)3 * *w * *h);
+  in.read(reinterpret_cast<char *>(top.data()), (std::streamsize)top.size());
+  if (!in) throw SceneError("truncated PPM: " + path);
+  // image readers of the reference return rows bottom-up (fileio/pngimage.cpp:210-221)
+  rgb->resize(top.size());
+  for (int y = 0; y < *h; y++) std::memcpy(&(*rgb)[(size_t)3 * *w * y], &top[(size_t)3 * *w * (*h - 1 - y)], (size_t)3 * *w);
 }
 
 void load_cubemap_ppm(const std::string &dir, SceneData *scene) {
   static const char *names[6] = {"posx", "negx", "posy", "negy", "posz", "negz"};  // TraceUI.cc:72-75
   for (int f = 0; f < 6; f++) {
     std::string path = dir + "/" + names[f] + ".ppm";
-    std::ifstream in(path, std::ios::binary);
-    if (!in) throw SceneError("Cannot locate all six cubemap files (missing " + path + ")");
-    std::string magic;
-    int w = 0, h = 0, maxv = 0;
-    in >> magic >> w >> h >> maxv;
-    in.get();
-    if (magic != "P6" || w <= 0 || h <= 0 || maxv != 255) throw SceneError("unsupported PPM: " + path);
-    std::vector<uint8_t> top((size_t)3 * w * h);
-    in.read(reinterpret_cast<char *>(top.data()), (std::streamsize)top.size());
-    if (!in) throw SceneError("truncated PPM: " + path);
-    // image readers of the reference return rows bottom-up (fileio/pngimage.cpp:210-221)
-    scene->cube_rgb[f].resize(top.size());
-    for (int y = 0; y < h; y++)
-      std::memcpy(&scene->cube_rgb[f][(size_t)3 * w * y], &top[(size_t)3 * w * (h - 1 - y)], (size_t)3 * w);
+    {
+      std::ifstream probe(path, std::ios::binary);
+      if (!probe) throw SceneError("Cannot locate all six cubemap files (missing " + path + ")");
+    }
+    int w = 0, h = 0;
+    read_ppm(path, &w, &h, &scene->cube_rgb[f]);
     scene->cube_w[f] = w;
     scene->cube_h[f] = h;
   }

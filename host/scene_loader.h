@@ -46,6 +46,7 @@ struct MeshData {
   std::vector<double> vertices;
   std::vector<int32_t> faces;
   std::vector<double> normals;
+  std::vector<double> uvs;  // 2 per vertex, or empty (the "UV" key)
 };
 
 struct SceneData {
@@ -58,6 +59,9 @@ struct SceneData {
   // cubemap faces (+x,-x,+y,-y,+z,-z), RGB8, row 0 = bottom; empty = none
   std::vector<uint8_t> cube_rgb[6];
   int cube_w[6] = {0, 0, 0, 0, 0, 0}, cube_h[6] = {0, 0, 0, 0, 0, 0};
+  // material textures ({"mapped": file}), RGB8, row 0 = bottom
+  struct Texture { std::string path; int w = 0, h = 0; std::vector<uint8_t> rgb; };
+  std::vector<Texture> textures;
 
   // Views for mipt_upload_scene; valid while *this is alive and unchanged.
   mipt_scene_desc describe();
@@ -65,6 +69,7 @@ struct SceneData {
  private:
   std::vector<mipt_mesh> mesh_views_;
   mipt_image cube_views_[6];
+  std::vector<mipt_image> texture_views_;
 };
 
 struct SceneError : std::runtime_error {
@@ -73,7 +78,13 @@ struct SceneError : std::runtime_error {
 
 // JsonParser::parseScene (JsonParser.cpp:447-515).  Throws SceneError / JsonError.
 SceneData load_scene_file(const std::string &path);
-SceneData parse_scene(const Json &root);
+// scene_dir: where {"mapped": file} textures are looked up (the scene file's directory,
+// JsonParser.cpp:95-96).  This host reads binary PPM (P6) textures only.
+SceneData parse_scene(const Json &root, const std::string &scene_dir = ".");
+
+// One binary PPM (P6, maxval 255) -> RGB8 with rows bottom-up, as the reference's image
+// readers return them (fileio/pngimage.cpp:210-221).
+void read_ppm(const std::string &path, int *w, int *h, std::vector<uint8_t> *rgb);
 
 // Six binary PPM (P6) files posx/negx/posy/negy/posz/negz.ppm in `dir` -> cubemap.
 void load_cubemap_ppm(const std::string &dir, SceneData *scene);

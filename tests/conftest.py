@@ -8,7 +8,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
-SCENE_NAMES = ("spheres", "spheresDirectional", "cornellBoxes", "hitchcockBRDF", "singleSphere", "areaLight", "room")
+SCENE_NAMES = ("spheres", "spheresDirectional", "cornellBoxes", "hitchcockBRDF", "singleSphere", "areaLight", "room", "russianRouletteTest")
 
 
 def pytest_configure(config):

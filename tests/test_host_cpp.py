@@ -61,6 +61,12 @@ def parse_dump(text):
             f = np.array(tok[4 + 3 * nv:4 + 3 * nv + 3 * nf], int)
             n = np.array(tok[4 + 3 * nv + 3 * nf:], float) if hn else None
             out["meshes"].append((v, f, n))
+        elif tok[0] == "mattex":
+            out.setdefault("mattex", []).append((int(tok[1]), int(tok[2])))
+        elif tok[0] == "uv":
+            out.setdefault("uvs", []).append(np.array(tok[1:], float))
+        elif tok[0] == "texture":
+            out.setdefault("textures", []).append([int(x) for x in tok[1:]])
         elif tok[0] == "light":
             out["lights"].append((int(tok[1]), np.array(tok[2:], float)))
     return out
@@ -84,6 +90,34 @@ def test_cpp_loader_matches_python_loader(host_bins, scene_file):
     for (_, vals), L in zip(d["lights"], sc.lights):
         want = np.concatenate([L.color, L.position, L.direction, L.u, L.v, [L.uL, L.vL], L.atten.astype(float)])
         assert np.allclose(vals, want, rtol=1e-7)
+
+
+def test_cpp_loader_reads_uvs_and_ppm_textures(host_bins, tmp_path):
+    # a mapped diffuse colour on a mesh with UV coordinates; the C++ host reads binary PPM textures
+    tex = np.random.RandomState(5).randint(0, 256, size=(4, 6, 3)).astype(np.uint8)  # rows top-down in the file
+    with open(tmp_path / "tex.ppm", "wb") as fh:
+        fh.write(b"P6\n6 4\n255\n" + tex.tobytes())
+    scene = [
+        {"camera": {"position": [0.0, 0.0, 4.0], "viewdir": [0.0, 0.0, -1.0], "updir": [0.0, 1.0, 0.0]}},
+        {"material": {"ambient": {"mapped": "tex.ppm"}}},
+        {"tri_mesh": {"points": [[0, 0, 0], [1, 0, 0], [1, 1, 0]], "faces": [[0, 1, 2]], "UV": [[0, 1], [1, 1], [1, 0]],
+                      "material": {"diffuse": {"mapped": "tex.ppm"}, "normal": {"mapped": "tex.ppm"}}}},
+        {"square": {"material": {"ambient": {"constant": [0.1, 0.2, 0.3]}}}},
+    ]
+    path = tmp_path / "scene.json"
+    path.write_text(json.dumps(scene))
+    d = parse_dump(subprocess.check_output([os.path.join(host_bins, "dump_scene"), str(path)]).decode())
+    sc = load_json_scene(str(path))
+    assert d["mattex"] == [(m.kd_texture, m.ka_texture) for m in sc.materials] == [(1, 1), (0, 0)]
+    assert np.allclose(d["uvs"][0], sc.meshes[0].uvs.ravel())
+    assert len(d["textures"]) == len(sc.textures) == 1
+    w, h, _, r, g, b = d["textures"][0]
+    assert (w, h) == (6, 4) and [r, g, b] == list(sc.textures[0][0, 0]) == list(tex[-1, 0])  # row 0 = bottom row of the file
+    # other formats are refused by this host, with the reference's wording
+    scene[1] = {"material": {"ambient": {"mapped": "tex.png"}}}
+    path.write_text(json.dumps(scene))
+    r = subprocess.run([os.path.join(host_bins, "dump_scene"), str(path)], capture_output=True)
+    assert r.returncode == 2 and b"Unable to load texture map" in r.stderr
 
 
 def test_cpp_loader_reports_errors(host_bins, tmp_path):

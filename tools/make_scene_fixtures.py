@@ -23,6 +23,7 @@ SCENES = {
     "singleSphere": "pathTracer/singleSphere.json",
     "areaLight": "pathTracer/areaLight.json",
     "room": "custom/room.json",
+    "russianRouletteTest": "custom/russianRouletteTest.json",
 }
 
 if __name__ == "__main__":
