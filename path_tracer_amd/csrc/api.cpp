@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -12,6 +13,7 @@
 #include <vector>
 
 #include "../../include/mipt.h"
+#include "gpu_build.h"
 #include "kernels.h"
 #include "scene_build.h"
 
@@ -325,8 +327,15 @@ int mipt_upload_scene(mipt_ctx *c, const mipt_scene_desc *desc) {
   std::string err;
   HostScene &H = c->host;
   int rcode;
+  // MIPT_BUILDER=gpu: build the BVH on the GPU (linear BVH, milliseconds, slower to traverse)
+  // instead of the host's binned SAH; small scenes always use the host builder
+  const char *bsel = std::getenv("MIPT_BUILDER");
+  int64_t prim_guess = desc ? desc->n_objects : 0;
+  if (desc && desc->meshes)
+    for (int k = 0; k < desc->n_meshes; k++) prim_guess += desc->meshes[k].n_faces;
+  const bool gpu_build = bsel && std::strcmp(bsel, "gpu") == 0 && prim_guess >= 4096;
   try {
-    rcode = build_host_scene(desc, &H, &err);
+    rcode = build_host_scene(desc, &H, &err, !gpu_build);
   } catch (const std::bad_alloc &) {
     return set_err(c, MIPT_ERR_NOMEM, "out of host memory while building the scene");
   }
@@ -334,13 +343,82 @@ int mipt_upload_scene(mipt_ctx *c, const mipt_scene_desc *desc) {
   SceneDev &D = c->dev;
   std::memset(&D, 0, sizeof(D));
   int r;
-  if ((r = upload(c, H.nodes, &D.nodes)) != MIPT_OK) return r;
-  if ((r = upload(c, H.tris, &D.tris)) != MIPT_OK) return r;
-  if (!H.tri_normals.empty()) {
-    if ((r = upload(c, H.tri_normals, &D.tri_normals)) != MIPT_OK) return r;
-  }
-  if (!H.tri_uvs.empty()) {
-    if ((r = upload(c, H.tri_uvs, &D.tri_uvs)) != MIPT_OK) return r;
+  if (gpu_build && H.prim_info.size() >= 3) {
+    // flat arrays in reference order -> tree and leaf order on the device
+    const uint32_t n = (uint32_t)H.prim_info.size();
+    std::vector<void *> staging;
+    auto stage = [&](const void *src, size_t bytes) -> void * {
+      void *p = nullptr;
+      if (hipMalloc(&p, bytes ? bytes : 16) != hipSuccess) return nullptr;
+      staging.push_back(p);
+      if (bytes && hipMemcpy(p, src, bytes, hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+      return p;
+    };
+    auto drop_staging = [&]() { for (void *p : staging) (void)hipFree(p); };
+    void *s_boxes = stage(H.prim_boxes.data(), H.prim_boxes.size() * sizeof(float));
+    void *s_info = stage(H.prim_info.data(), (size_t)n * sizeof(uint32_t));
+    void *s_tris = stage(H.tris.data(), (size_t)n * sizeof(Tri));
+    void *s_norm = H.tri_normals.empty() ? nullptr : stage(H.tri_normals.data(), (size_t)n * sizeof(TriNormals));
+    void *s_uv = H.tri_uvs.empty() ? nullptr : stage(H.tri_uvs.data(), (size_t)n * sizeof(TriUV));
+    if (!s_boxes || !s_info || !s_tris || (!H.tri_normals.empty() && !s_norm) || (!H.tri_uvs.empty() && !s_uv)) {
+      drop_staging();
+      return set_err(c, MIPT_ERR_NOMEM, "out of device memory while staging the scene");
+    }
+    int leaf_max = 2;
+    if (const char *lm = std::getenv("MIPT_LEAF_MAX")) {
+      int v = std::atoi(lm);
+      if (v >= 1 && v <= 8) leaf_max = v;
+    }
+    GpuBvh g;
+    auto t_build = std::chrono::steady_clock::now();
+    hipError_t ge = gpu_build_bvh((const float *)s_boxes, (const uint32_t *)s_info, n, H.bounds_min, H.bounds_max, leaf_max, &g, nullptr);
+    if (std::getenv("MIPT_BUILD_TIMING"))
+      std::fprintf(stderr, "[mipt build] %-28s %8.3f s (%d nodes, %d levels)\n", "GPU linear BVH",
+                   std::chrono::duration<double>(std::chrono::steady_clock::now() - t_build).count(), g.n_nodes, g.levels);
+    if (ge != hipSuccess) {
+      drop_staging();
+      return set_err(c, ge == hipErrorOutOfMemory ? MIPT_ERR_NOMEM : MIPT_ERR_DEVICE, "GPU BVH build: %s", hipGetErrorString(ge));
+    }
+    c->scene_allocs.push_back(g.nodes);
+    c->scene_allocs.push_back(g.order);
+    c->scene_bytes += (int64_t)n * (int64_t)(sizeof(Node4) + sizeof(uint32_t));
+    D.nodes = g.nodes;
+    D.ref_order = g.order;  // the flat arrays were in reference order
+    auto gathered = [&](const void *src, uint32_t bytes) -> void * {
+      void *p = nullptr;
+      if (hipMalloc(&p, (size_t)n * bytes) != hipSuccess) return nullptr;
+      c->scene_allocs.push_back(p);
+      c->scene_bytes += (int64_t)n * bytes;
+      gpu_gather_records(p, src, g.order, n, bytes, nullptr);
+      return p;
+    };
+    D.tris = (const Tri *)gathered(s_tris, sizeof(Tri));
+    D.prim_info = (const uint32_t *)gathered(s_info, sizeof(uint32_t));
+    if (s_norm) D.tri_normals = (const TriNormals *)gathered(s_norm, sizeof(TriNormals));
+    if (s_uv) D.tri_uvs = (const TriUV *)gathered(s_uv, sizeof(TriUV));
+    hipError_t se = hipDeviceSynchronize();
+    drop_staging();
+    if (!D.tris || !D.prim_info || (s_norm && !D.tri_normals) || (s_uv && !D.tri_uvs)) return set_err(c, MIPT_ERR_NOMEM, "out of device memory for the scene");
+    if (se != hipSuccess) return set_err(c, MIPT_ERR_DEVICE, "GPU BVH build: %s", hipGetErrorString(se));
+    H.n_analytic = g.n_analytic;
+    H.max_depth = g.levels;
+    H.stack_need = 3 * g.levels + 1;  // at most three siblings wait per level
+    c->n_nodes = g.n_nodes;
+  } else {
+    if (gpu_build) {  // too few primitives after dropping degenerate faces: host builder
+      if ((rcode = build_host_scene(desc, &H, &err, true)) != MIPT_OK) return set_err(c, rcode, "%s", err.c_str());
+    }
+    if ((r = upload(c, H.nodes, &D.nodes)) != MIPT_OK) return r;
+    if ((r = upload(c, H.tris, &D.tris)) != MIPT_OK) return r;
+    if (!H.tri_normals.empty()) {
+      if ((r = upload(c, H.tri_normals, &D.tri_normals)) != MIPT_OK) return r;
+    }
+    if (!H.tri_uvs.empty()) {
+      if ((r = upload(c, H.tri_uvs, &D.tri_uvs)) != MIPT_OK) return r;
+    }
+    if ((r = upload(c, H.prim_info, &D.prim_info)) != MIPT_OK) return r;
+    if ((r = upload(c, H.ref_order, &D.ref_order)) != MIPT_OK) return r;
+    c->n_nodes = (int64_t)H.nodes.size();
   }
   if (!H.tex_rgb.empty()) {
     std::vector<TexRec> table;
@@ -352,8 +430,6 @@ int mipt_upload_scene(mipt_ctx *c, const mipt_scene_desc *desc) {
     if ((r = upload(c, table, &D.textures)) != MIPT_OK) return r;
     D.n_textures = (int)table.size();
   }
-  if ((r = upload(c, H.prim_info, &D.prim_info)) != MIPT_OK) return r;
-  if ((r = upload(c, H.ref_order, &D.ref_order)) != MIPT_OK) return r;
   if ((r = upload(c, H.objects, &D.objects)) != MIPT_OK) return r;
   if ((r = upload(c, H.materials, &D.materials)) != MIPT_OK) return r;
   if ((r = upload(c, H.lights, &D.lights)) != MIPT_OK) return r;
@@ -396,7 +472,6 @@ int mipt_upload_scene(mipt_ctx *c, const mipt_scene_desc *desc) {
     }
   }
   c->n_prims = (int64_t)H.prim_info.size();
-  c->n_nodes = (int64_t)H.nodes.size();
   c->lights_host = H.lights;
   c->lights_area_samples = -1;
   // drop the big host copies

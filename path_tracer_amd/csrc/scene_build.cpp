@@ -122,6 +122,11 @@ inline float round_down(double v) {
   if ((double)f > v) f = std::nextafterf(f, -std::numeric_limits<float>::infinity());
   return f;
 }
+inline float round_up(double v) {
+  float f = (float)v;
+  if ((double)f < v) f = std::nextafterf(f, std::numeric_limits<float>::infinity());
+  return f;
+}
 
 // ------------------------------------------------------------- SAH builder ----
 struct BuildPrim {
@@ -437,22 +442,15 @@ struct Collapser {
 
 }  // namespace
 
-void reference_visit_order(const std::vector<double> &boxes, std::vector<uint32_t> *order_out) {
-  size_t n = boxes.size() / 6;
-  std::vector<uint32_t> &order = *order_out;
-  order.resize(n);
-  for (size_t i = 0; i < n; i++) order[i] = (uint32_t)i;
-  if (n == 0) return;
-  struct Range { size_t begin, amt; };
-  std::vector<Range> todo;
-  todo.push_back({0, n});
+namespace {
+// One range of BVH<T>::makeBVH's in-place partition (bvh.h:40-110) on order[begin, begin + amt).
+// The two halves touch disjoint parts of `order`, so large ones go to another thread.
+void visit_order_range(const std::vector<double> &boxes, std::vector<uint32_t> &order, size_t begin, size_t amt, int forks) {
   auto bmin = [&](size_t k, int a) { return boxes[6 * (size_t)order[k] + a]; };
   auto bmax = [&](size_t k, int a) { return boxes[6 * (size_t)order[k] + 3 + a]; };
-  while (!todo.empty()) {
-    Range rg = todo.back();
-    todo.pop_back();
-    if (rg.amt <= 2) continue;  // bvh.h:49-52
-    size_t begin = rg.begin, end = rg.begin + rg.amt - 1;
+  while (true) {
+    if (amt <= 2) return;  // bvh.h:49-52
+    size_t end = begin + amt - 1;
     double mn[3], mx[3];
     for (int a = 0; a < 3; a++) { mn[a] = bmin(begin, a); mx[a] = bmax(begin, a); }
     for (size_t k = begin + 1; k <= end; k++)
@@ -477,10 +475,28 @@ void reference_visit_order(const std::vector<double> &boxes, std::vector<uint32_
       }
     }
     size_t leftCount = (size_t)i - begin;
-    if (leftCount == 0 || leftCount == rg.amt) continue;  // bvh.h:97-100: stays one leaf
-    todo.push_back({begin, leftCount});
-    todo.push_back({(size_t)i, rg.amt - leftCount});
+    if (leftCount == 0 || leftCount == amt) return;  // bvh.h:97-100: stays one leaf
+    size_t rightBegin = (size_t)i, rightCount = amt - leftCount;
+    if (forks > 0 && amt >= ((size_t)1 << 15)) {
+      auto left = std::async(std::launch::async, [&, begin, leftCount, forks]() { visit_order_range(boxes, order, begin, leftCount, forks - 1); });
+      visit_order_range(boxes, order, rightBegin, rightCount, forks - 1);
+      left.get();
+      return;
+    }
+    visit_order_range(boxes, order, begin, leftCount, 0);
+    begin = rightBegin;  // the right half in this frame: no deep recursion on lopsided splits
+    amt = rightCount;
   }
+}
+}  // namespace
+
+void reference_visit_order(const std::vector<double> &boxes, std::vector<uint32_t> *order_out) {
+  size_t n = boxes.size() / 6;
+  std::vector<uint32_t> &order = *order_out;
+  order.resize(n);
+  for (size_t i = 0; i < n; i++) order[i] = (uint32_t)i;
+  if (n == 0) return;
+  visit_order_range(boxes, order, 0, n, 5);
 }
 
 namespace {
@@ -496,7 +512,7 @@ struct PhaseTimer {
 };
 }  // namespace
 
-int build_host_scene(const mipt_scene_desc *d, HostScene *out, std::string *err) {
+int build_host_scene(const mipt_scene_desc *d, HostScene *out, std::string *err, bool build_tree) {
   PhaseTimer timer;
   HostScene &S = *out;
   S = HostScene();
@@ -739,6 +755,28 @@ int build_host_scene(const mipt_scene_desc *d, HostScene *out, std::string *err)
   timer.lap("primitives, reference order");
   // ---- BVH over all primitives ---------------------------------------------------
   size_t nPrims = prims.size();
+  Box6 rootBox;
+  rootBox.reset();
+  if (!build_tree) {
+    // flat mode: arrays stay in reference order, the tree is built on the GPU
+    S.tris = std::move(trisRef);
+    S.prim_info = std::move(infoRef);
+    if (anySmooth) S.tri_normals = std::move(normsRef);
+    if (anyUV) S.tri_uvs = std::move(uvsRef);
+    S.ref_order.resize(nPrims);
+    S.prim_boxes.resize(6 * nPrims);
+    for (size_t s = 0; s < nPrims; s++) {
+      S.ref_order[s] = (uint32_t)s;
+      bool empty = prims[s].box.mx[0] < prims[s].box.mn[0];
+      for (int a = 0; a < 3; a++) {
+        S.prim_boxes[6 * s + a] = empty ? 0.0f : round_down(prims[s].box.mn[a]);
+        S.prim_boxes[6 * s + 3 + a] = empty ? 0.0f : round_up(prims[s].box.mx[a]);
+      }
+      if (!empty) rootBox.grow(prims[s].box);
+      if ((S.prim_info[s] >> 30) != KIND_TRI) S.n_analytic++;
+    }
+    timer.lap("flat arrays");
+  } else {
   size_t nAnalytic = (size_t)(std::stable_partition(prims.begin(), prims.end(), [&](const BuildPrim &p) { return (infoRef[p.id] >> 30) != KIND_TRI; }) -
                               prims.begin());
   S.n_analytic = (int)nAnalytic;
@@ -749,8 +787,6 @@ int build_host_scene(const mipt_scene_desc *d, HostScene *out, std::string *err)
   }
   builder.nodes.reserve(nPrims / 2 + 16);
   builder.forks = 6;  // up to 64 tasks: SAH splits are uneven, many small tasks balance the threads
-  Box6 rootBox;
-  rootBox.reset();
   Collapser wide(builder.nodes);
   timer.lap("partition by kind");
   int need = 0;
@@ -809,6 +845,11 @@ int build_host_scene(const mipt_scene_desc *d, HostScene *out, std::string *err)
     if (anyUV) S.tri_uvs[s] = uvsRef[id];
   }
   timer.lap("leaf-order arrays");
+  }
+  for (int a = 0; a < 3; a++) {
+    S.bounds_min[a] = nPrims ? rootBox.mn[a] : 0.0;
+    S.bounds_max[a] = nPrims ? rootBox.mx[a] : 0.0;
+  }
   double R = 0;
   if (nPrims)
     for (int a = 0; a < 3; a++) R = std::max(R, std::max(std::fabs(rootBox.mn[a]), std::fabs(rootBox.mx[a])));

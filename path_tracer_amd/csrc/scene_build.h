@@ -21,6 +21,8 @@ struct HostScene {
   std::vector<uint32_t> prim_info;     // kind << 30 | object
   int n_analytic = 0;                  // primitives [0, n_analytic) are spheres/boxes/squares, the rest triangles
   std::vector<uint32_t> ref_order;     // reference visiting order of each primitive (tie-break key)
+  std::vector<float> prim_boxes;       // flat mode only: 6 floats per primitive (min, max), rounded outward
+  double bounds_min[3] = {0, 0, 0}, bounds_max[3] = {0, 0, 0};  // scene bounds
   std::vector<ObjRec> objects;
   std::vector<MatRec> materials;
   std::vector<LightRec> lights;
@@ -36,8 +38,10 @@ struct HostScene {
   std::vector<int> tex_w, tex_h;
 };
 
-// Returns MIPT_OK or an error code with `err` set.
-int build_host_scene(const mipt_scene_desc *desc, HostScene *out, std::string *err);
+// Returns MIPT_OK or an error code with `err` set.  build_tree = false ("flat mode") leaves
+// `nodes` empty and the primitive arrays in reference order (ref_order[s] = s), with
+// prim_boxes filled: the input of the GPU builder (gpu_build.h).
+int build_host_scene(const mipt_scene_desc *desc, HostScene *out, std::string *err, bool build_tree = true);
 
 // Replays BVH<T>::makeBVH (scene/bvh.h:40-110) on a list of boxes and returns the
 // final allNodes order: order[k] = index of the k-th item the reference's

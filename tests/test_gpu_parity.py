@@ -105,6 +105,32 @@ def test_traversal_stack_overflow_area(gpu, oracle_lib, monkeypatch):
     assert_images_match(f32, ref, rgb8, ref8, frac=0.995)
 
 
+def test_gpu_built_linear_bvh_gives_the_same_results(gpu, oracle_lib, monkeypatch):
+    # MIPT_BUILDER=gpu builds the tree on the device (Morton codes, radix tree, four-wide collapse);
+    # the box tests only cull, so hits and images must not depend on which builder made the tree
+    from path_tracer_amd import synth
+
+    sc = synth.make_scene(30000, seed=21)
+    orc = oracle_lib.Oracle(sc)
+    monkeypatch.setenv("MIPT_BUILDER", "gpu")
+    upload(gpu, sc)
+    monkeypatch.delenv("MIPT_BUILDER")
+    stats = gpu.scene_stats()
+    assert stats["nodes"] > 1000
+    org, d = U.camera_rays(sc, 30000, seed=9)
+    res = orc.intersect(org, d)
+    assert_rays_match(gpu.intersect(org, d), res, min_same=0.9999)
+    t, prim, n = res
+    hit = prim >= 0
+    P = org[hit] + t[hit, None] * d[hit]
+    d2 = U.random_dirs(len(P), seed=10)
+    assert_rays_match(gpu.intersect(P + d2 * 1e-8, d2), orc.intersect(P + d2 * 1e-8, d2), min_same=0.9999)
+    p = abi.default_params(96, 54, spp=2, seed=4)
+    f32, rgb8 = gpu.render(p)
+    ref, ref8 = orc.render(p, threads=8, want_rgb8=True)
+    assert_images_match(f32, ref, rgb8, ref8, frac=0.995)
+
+
 def test_transformed_mesh_matches_local_space_reference(gpu, oracle_lib):
     # the library pre-transforms triangles to world space; the reference intersects in the
     # mesh's local space (scene.cpp:13-40).  Non-uniform scale + rotation + mirroring.
