@@ -218,6 +218,7 @@ def main():
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
             "traffic": load_traffic(args.workload, dominant),
+            "utilisation": load_utilisation(args.workload, dominant),
             "avg_launch_ms": avg_launch_ms,
             "launches_per_step": launches_step,
             "algorithmic_bytes_per_sample": (algorithmic_bytes(cnt, "intersect") + algorithmic_bytes(cnt, "shadow") + 64 * cnt["shaded_hits"]) / step_samples,
@@ -296,6 +297,19 @@ def load_traffic(workload, kernel):
         with open(path) as fh:
             t = json.load(fh)
         return t.get(workload, {}).get("k_shadow_any" if kernel == "shadow" else "k_intersect", {}).get("hbm_bytes_per_launch")
+    except (OSError, ValueError):
+        return None
+
+
+def load_utilisation(workload, kernel):
+    """VALU busy share, VALU lane utilisation, waves per SIMD, TA / TCP busy shares and cache
+    hit rates of the dominant kernel, from the committed rocprofv3 counter passes of this
+    workload (profiles/r01_derived.json, made by tools/derive_metrics.py); None if absent."""
+    if workload != "synth1m":
+        return None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_derived.json")) as fh:
+            return json.load(fh).get("k_shadow_any" if kernel == "shadow" else "k_intersect")
     except (OSError, ValueError):
         return None
 
