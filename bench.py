@@ -43,6 +43,9 @@ FIXTURE_WORKLOADS = {
     "spheres": ("spheres", 512, 512, 100),
     "cornell": ("cornellBoxes", 1024, 1024, 1024),
     "hitchcock": ("hitchcockBRDF", 1920, 1080, 2048),
+    # authored variants: area light instead of the point light; boxes as triangle meshes
+    "cornell_area": ("cornellBoxes", 1024, 1024, 1024),
+    "hitchcock_mesh": ("hitchcockBRDF", 1920, 1080, 2048),
 }
 
 
@@ -59,6 +62,10 @@ def build_scene(name, triangles=None):
         return sc, w, h, spp, label
     fx, w, h, spp = FIXTURE_WORKLOADS[name]
     sc = Scene.load_npz(os.path.join(ROOT, "tests", "golden", "scenes", fx + ".npz"))
+    if name == "cornell_area":
+        return synth.cornell_area_light(sc), w, h, spp, f"{fx} with a rectangular area light in place of the point light, {w}x{h}"
+    if name == "hitchcock_mesh":
+        return synth.tessellate_boxes(sc), w, h, spp, f"{fx} with its 140 boxes as triangle meshes, {w}x{h}"
     return sc, w, h, spp, f"{fx} (reference demo scene), {w}x{h}"
 
 

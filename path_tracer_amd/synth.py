@@ -199,3 +199,65 @@ def make_sky_cubemap(size: int = 64):
 def small_mesh_scene(seed: int = 7, n_triangles: int = 20000, smooth: bool = True) -> Scene:
     """A small version of the same layout for parity tests (a CPU render finishes in seconds)."""
     return make_scene(n_triangles=n_triangles, seed=seed)
+
+
+# ------------------------------------------------------------------ variants of the demo scenes
+_CUBE_VERTS = np.array([[x, y, z] for z in (-0.5, 0.5) for y in (-0.5, 0.5) for x in (-0.5, 0.5)], dtype=np.float64)
+# two triangles per face of the unit cube (Box.cpp:9-13 spans [-0.5, 0.5]^3), outward winding
+_CUBE_FACES = np.array(
+    [[0, 2, 3], [0, 3, 1],  # z = -0.5
+     [4, 5, 7], [4, 7, 6],  # z = +0.5
+     [0, 1, 5], [0, 5, 4],  # y = -0.5
+     [2, 6, 7], [2, 7, 3],  # y = +0.5
+     [0, 4, 6], [0, 6, 2],  # x = -0.5
+     [1, 3, 7], [1, 7, 5]],  # x = +0.5
+    dtype=np.int32)
+
+
+def with_rect_area_light(scene: Scene, position, u, v, uL: float, vL: float, color=(1.0, 1.0, 1.0),
+                         atten=(0.25, 0.0, 0.0), replace_point_lights: bool = True) -> Scene:
+    """A copy of `scene` lit by one rectangular area light (light.cpp:92-140), which costs
+    `area_samples` shadow rays per shaded hit where a point light costs one.  The demo Cornell
+    box ships with a point light only; this is the area-light variant of it."""
+    import copy
+
+    out = copy.deepcopy(scene)
+    if replace_point_lights:
+        out.lights = [L for L in out.lights if L.type != abi.LIGHT_POINT]
+    out.lights.append(LightRec(
+        abi.LIGHT_RECT_AREA, np.asarray(color, dtype=np.float64), position=np.asarray(position, dtype=np.float64),
+        u=np.asarray(u, dtype=np.float64), v=np.asarray(v, dtype=np.float64), uL=float(uL), vL=float(vL),
+        atten=np.asarray(atten, dtype=np.float32)))
+    return out
+
+
+def cornell_area_light(scene: Scene) -> Scene:
+    """cornellBoxes with its point light (0, 9, -8) swapped for a strip light at the same place.
+    The sampled points are corner + uVec * uI + vVec + (vI, vI, vI) (light.cpp:105-111), so the
+    strip is laid out for that: 6 long in x, and vL small enough that the diagonal term stays
+    under the ceiling (y = 9.6)."""
+    return with_rect_area_light(scene, position=(-3.0, 8.5, -9.0), u=(1.0, 0.0, 0.0), v=(0.0, 0.0, 1.0), uL=6.0, vL=0.5)
+
+
+def tessellate_boxes(scene: Scene) -> Scene:
+    """A copy of `scene` with every Box replaced by a 12-triangle mesh of the same surface, its
+    vertices already in world space the way the scene reader stores mesh vertices
+    (JsonParser.cpp:253-262).  Mirroring transforms get their winding flipped so the face
+    normals (trimesh.cpp:102-107) keep pointing out of the box."""
+    import copy
+
+    out = copy.deepcopy(scene)
+    objects = []
+    for o in out.objects:
+        if o.type != abi.OBJ_BOX:
+            objects.append(o)
+            continue
+        m = np.asarray(o.xform, dtype=np.float64)
+        verts = _CUBE_VERTS @ m[:3, :3].T + m[:3, 3]
+        faces = _CUBE_FACES.copy()
+        if np.linalg.det(m[:3, :3]) < 0:
+            faces = faces[:, ::-1].copy()
+        out.meshes.append(MeshRec(np.ascontiguousarray(verts), np.ascontiguousarray(faces)))
+        objects.append(ObjectRec(abi.OBJ_TRIMESH, o.material, len(out.meshes) - 1, np.eye(4)))
+    out.objects = objects
+    return out

@@ -254,6 +254,31 @@ def test_mesh_scene_images(gpu, oracle_lib):
     assert_images_match(f32, ref, rgb8, ref8, frac=0.995)
 
 
+@pytest.mark.parametrize("variant", ["cornell_area_light", "hitchcock_tessellated"])
+def test_authored_variants_of_the_demo_scenes(variant, gpu, oracle_lib, scenes):
+    """cornellBoxes under a rectangular area light (10 shadow rays per hit) and hitchcockBRDF
+    with every box as 12 triangles: per-ray hits, a deterministic frame and a frame with the
+    reference's settings."""
+    from path_tracer_amd import synth
+
+    sc = synth.cornell_area_light(scenes("cornellBoxes")) if variant == "cornell_area_light" else synth.tessellate_boxes(scenes("hitchcockBRDF"))
+    orc = oracle_lib.Oracle(sc)
+    upload(gpu, sc)
+    org, d = U.camera_rays(sc, 20000, seed=5)
+    assert_rays_match(gpu.intersect(org, d), orc.intersect(org, d))
+    p = abi.default_params(128, 96, spp=1, rr_q=0.0, max_depth=4, flags=abi.FLAG_FIXED_AREA_PATTERN)
+    f32, rgb8 = gpu.render(p)
+    ref, ref8 = orc.render(p, threads=8, want_rgb8=True)
+    assert ref.mean() > 0.01
+    assert_images_match(f32, ref, rgb8, ref8)
+    p = abi.default_params(96, 96, spp=8)
+    f32, rgb8 = gpu.render(p)
+    ref, ref8, cnt = orc.render(p, threads=8, want_rgb8=True, want_counters=True)
+    assert_images_match(f32, ref, rgb8, ref8)
+    if variant == "cornell_area_light":
+        assert cnt["shadow_rays"] == 10 * cnt["shaded_hits"]
+
+
 def test_cubemap_environment(gpu, oracle_lib, scenes):
     from path_tracer_amd import synth
     import copy
