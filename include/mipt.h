@@ -85,7 +85,10 @@ typedef struct mipt_object {
  * vertex (the "UV" key, JsonParser.cpp:271-279; interpolated as
  * trimesh.cpp:165-172).  Hits on a mesh without uvs, and on spheres, have UV
  * (0, 0) (ray.h:71); squares and boxes set their own (Square.cpp:41,
- * Box.cpp:62-71). */
+ * Box.cpp:62-71).  colors is NULL or one RGB per vertex (OBJ files only,
+ * JsonParser.cpp:609-612): on a mesh WITHOUT uvs the hit's diffuse colour is
+ * the interpolated vertex colour instead of the material's (trimesh.cpp:170-189);
+ * with uvs the colours are never read. */
 typedef struct mipt_mesh {
   const double *vertices; /* 3 * n_vertices */
   int64_t n_vertices;
@@ -93,6 +96,7 @@ typedef struct mipt_mesh {
   int64_t n_faces;
   const double *normals; /* NULL or 3 * n_vertices */
   const double *uvs;     /* NULL or 2 * n_vertices */
+  const double *colors;  /* NULL or 3 * n_vertices */
 } mipt_mesh;
 
 /* A light, fields as the JSON parser hands them to the constructors

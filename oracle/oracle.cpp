@@ -231,6 +231,8 @@ struct Isect {  // ray.h:67-145 (fields used on this path)
   int prim = -1;  // reference-order primitive index
   int mat = -1;
   double u = 0.0, v = 0.0;  // uvCoordinates, default-constructed to (0, 0) (ray.h:71)
+  bool hasColor = false;    // the hit carries its own material copy with kd replaced (trimesh.cpp:179-189)
+  V3 color;
 };
 
 struct Counters {
@@ -306,6 +308,7 @@ struct BVH {
 struct Mesh {
   std::vector<V3> verts, normals;
   std::vector<double> uvs;  // 2 per vertex, or empty
+  std::vector<V3> colors;   // vertColors, or empty
   struct Face {
     int ids[3];
     V3 normal;
@@ -370,7 +373,8 @@ struct orc_scene {
   // through a texture: the material as the hit sees it.
   Material materialAt(const Isect &i) const {
     Material m = materials[i.mat];
-    if (m.kdTex > 0) m.kd = textures[(size_t)m.kdTex - 1].mapped(i.u, i.v);
+    if (i.hasColor) m.kd = i.color;  // setDiffuse(interpolatedColor): a constant, whatever kd was
+    else if (m.kdTex > 0) m.kd = textures[(size_t)m.kdTex - 1].mapped(i.u, i.v);
     if (m.kaTex > 0) m.ka = textures[(size_t)m.kaTex - 1].mapped(i.u, i.v);
     return m;
   }
@@ -477,6 +481,12 @@ struct orc_scene {
       double uC = m.uvs[2 * (size_t)f.ids[2]] * w2, vC = m.uvs[2 * (size_t)f.ids[2] + 1] * w2;
       i.u = (uA + uB) + uC;
       i.v = (vA + vB) + vC;
+    } else if (!m.colors.empty()) {  // trimesh.cpp:179-189
+      V3 cA = m.colors[f.ids[0]] * w0;
+      V3 cB = m.colors[f.ids[1]] * w1;
+      V3 cC = m.colors[f.ids[2]] * w2;
+      i.color = (cA + cB) + cC;
+      i.hasColor = true;
     }
     i.t = t;
     return true;
@@ -498,6 +508,8 @@ struct orc_scene {
           i.N = test.N;
           i.u = test.u;
           i.v = test.v;
+          i.hasColor = test.hasColor;
+          i.color = test.color;
           i.prim = objPrimBase + nd.first + j;
         }
         hitAny |= check;
@@ -602,6 +614,8 @@ struct orc_scene {
               test.N = ft.N;
               test.u = ft.u;
               test.v = ft.v;
+              test.hasColor = ft.hasColor;
+              test.color = ft.color;
               test.prim = o.primBase + (int)fi;
             }
           }
@@ -934,6 +948,8 @@ orc_scene *orc_create(const mipt_scene_desc *d) {
       for (int64_t v = 0; v < src.n_vertices; v++) m.normals[v] = V3(src.normals[3 * v], src.normals[3 * v + 1], src.normals[3 * v + 2]);
     }
     if (src.uvs) m.uvs.assign(src.uvs, src.uvs + 2 * (size_t)src.n_vertices);
+    if (src.colors)
+      for (int64_t v = 0; v < src.n_vertices; v++) m.colors.push_back(V3(src.colors[3 * v], src.colors[3 * v + 1], src.colors[3 * v + 2]));
     std::vector<BBox> fboxes;
     for (int64_t f = 0; f < src.n_faces; f++) {
       int a = src.faces[3 * f], b = src.faces[3 * f + 1], c = src.faces[3 * f + 2];

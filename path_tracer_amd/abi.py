@@ -53,6 +53,7 @@ class Mesh(C.Structure):
         ("n_faces", C.c_int64),
         ("normals", C.POINTER(C.c_double)),
         ("uvs", C.POINTER(C.c_double)),
+        ("colors", C.POINTER(C.c_double)),
     ]
 
 

@@ -360,7 +360,9 @@ int mipt_upload_scene(mipt_ctx *c, const mipt_scene_desc *desc) {
     void *s_tris = stage(H.tris.data(), (size_t)n * sizeof(Tri));
     void *s_norm = H.tri_normals.empty() ? nullptr : stage(H.tri_normals.data(), (size_t)n * sizeof(TriNormals));
     void *s_uv = H.tri_uvs.empty() ? nullptr : stage(H.tri_uvs.data(), (size_t)n * sizeof(TriUV));
-    if (!s_boxes || !s_info || !s_tris || (!H.tri_normals.empty() && !s_norm) || (!H.tri_uvs.empty() && !s_uv)) {
+    void *s_col = H.tri_colors.empty() ? nullptr : stage(H.tri_colors.data(), (size_t)n * sizeof(TriColor));
+    if (!s_boxes || !s_info || !s_tris || (!H.tri_normals.empty() && !s_norm) || (!H.tri_uvs.empty() && !s_uv) ||
+        (!H.tri_colors.empty() && !s_col)) {
       drop_staging();
       return set_err(c, MIPT_ERR_NOMEM, "out of device memory while staging the scene");
     }
@@ -396,9 +398,10 @@ int mipt_upload_scene(mipt_ctx *c, const mipt_scene_desc *desc) {
     D.prim_info = (const uint32_t *)gathered(s_info, sizeof(uint32_t));
     if (s_norm) D.tri_normals = (const TriNormals *)gathered(s_norm, sizeof(TriNormals));
     if (s_uv) D.tri_uvs = (const TriUV *)gathered(s_uv, sizeof(TriUV));
+    if (s_col) D.tri_colors = (const TriColor *)gathered(s_col, sizeof(TriColor));
     hipError_t se = hipDeviceSynchronize();
     drop_staging();
-    if (!D.tris || !D.prim_info || (s_norm && !D.tri_normals) || (s_uv && !D.tri_uvs)) return set_err(c, MIPT_ERR_NOMEM, "out of device memory for the scene");
+    if (!D.tris || !D.prim_info || (s_norm && !D.tri_normals) || (s_uv && !D.tri_uvs) || (s_col && !D.tri_colors)) return set_err(c, MIPT_ERR_NOMEM, "out of device memory for the scene");
     if (se != hipSuccess) return set_err(c, MIPT_ERR_DEVICE, "GPU BVH build: %s", hipGetErrorString(se));
     H.n_analytic = g.n_analytic;
     H.max_depth = g.levels;
@@ -415,6 +418,9 @@ int mipt_upload_scene(mipt_ctx *c, const mipt_scene_desc *desc) {
     }
     if (!H.tri_uvs.empty()) {
       if ((r = upload(c, H.tri_uvs, &D.tri_uvs)) != MIPT_OK) return r;
+    }
+    if (!H.tri_colors.empty()) {
+      if ((r = upload(c, H.tri_colors, &D.tri_colors)) != MIPT_OK) return r;
     }
     if ((r = upload(c, H.prim_info, &D.prim_info)) != MIPT_OK) return r;
     if ((r = upload(c, H.ref_order, &D.ref_order)) != MIPT_OK) return r;
@@ -479,6 +485,7 @@ int mipt_upload_scene(mipt_ctx *c, const mipt_scene_desc *desc) {
   std::vector<Tri>().swap(H.tris);
   std::vector<TriNormals>().swap(H.tri_normals);
   std::vector<TriUV>().swap(H.tri_uvs);
+  std::vector<TriColor>().swap(H.tri_colors);
   std::vector<std::vector<uint8_t>>().swap(H.tex_rgb);
   std::vector<uint32_t>().swap(H.prim_info);
   std::vector<uint32_t>().swap(H.ref_order);

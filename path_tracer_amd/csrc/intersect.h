@@ -24,6 +24,7 @@ struct SceneDev {
   const Tri *tris;
   const TriNormals *tri_normals;  // may be null
   const TriUV *tri_uvs;           // may be null
+  const TriColor *tri_colors;     // may be null
   const TexRec *textures;         // material textures, n_textures of them
   int n_textures;
   const uint32_t *prim_info;
@@ -454,6 +455,21 @@ __device__ __forceinline__ void hit_uv(const SceneDev &S, int prim, d3 org, d3 d
     u = face < 3 ? 0.5 - lo : 0.5 + lo;
     v = 0.5 + hi;
   }
+}
+
+// Diffuse colour of a hit on a mesh that shades with per-vertex colours
+// (trimesh.cpp:179-189: a copy of the mesh's material with kd replaced); false elsewhere.
+__device__ __forceinline__ bool hit_vertex_color(const SceneDev &S, int prim, d3 org, d3 dir, d3 &kd) {
+  if (!S.tri_colors) return false;
+  uint32_t info = S.prim_info[prim];
+  if ((info >> 30) != KIND_TRI) return false;
+  const ObjRec *o = S.objects + (info & 0x3fffffffu);
+  double t, w1, w2;
+  if (!o->has_colors || !tri_hit(S.tris + prim, org, dir, t, w1, w2)) return false;
+  const TriColor *q = S.tri_colors + prim;
+  double w0 = 1 - w1 - w2;
+  kd = (ld3(q->ca) * w0 + ld3(q->cb) * w1) + ld3(q->cc) * w2;
+  return true;
 }
 
 }  // namespace mipt

@@ -286,6 +286,7 @@ __global__ void __launch_bounds__(kShadeBlock) k_shade(SceneDev S, RenderConst r
           if (m->kd_tex > 0) { const TexRec &tx = S.textures[m->kd_tex - 1]; kd = tex_mapped(tx.data, tx.w, tx.h, tu, tv); }
           if (m->ka_tex > 0) { const TexRec &tx = S.textures[m->ka_tex - 1]; ka = tex_mapped(tx.data, tx.w, tx.h, tu, tv); }
         }
+        if (S.tri_colors) hit_vertex_color(S, prim, o, d, kd);  // per-vertex colours replace kd, trimesh.cpp:179-189
         // tangent frame, RayTracer.cpp:236-241
         d3 Nt;
         if (fabs(N.x) > fabs(N.y)) Nt = d3{N.z, 0, -N.x} / sqrt(N.x * N.x + N.z * N.z);
@@ -692,6 +693,7 @@ __global__ void __launch_bounds__(kBlock) k_hit_material(SceneDev S, int64_t n, 
       hit_uv(S, h.prim, o, d, u, v);
       if (m->kd_tex > 0) { const TexRec &tx = S.textures[m->kd_tex - 1]; kd = tex_mapped(tx.data, tx.w, tx.h, u, v); }
       if (m->ka_tex > 0) { const TexRec &tx = S.textures[m->ka_tex - 1]; ka = tex_mapped(tx.data, tx.w, tx.h, u, v); }
+      hit_vertex_color(S, h.prim, o, d, kd);
     }
     uv[2 * idx] = u;
     uv[2 * idx + 1] = v;

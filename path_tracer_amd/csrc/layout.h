@@ -59,6 +59,13 @@ struct alignas(8) TriUV {
   double ua, va, ub, vb, uc, vc;
 };
 
+// Per-vertex colours of one triangle (only an OBJ file can give a mesh colours,
+// JsonParser.cpp:609-612): on a mesh without UV coordinates the hit's diffuse colour is
+// ca * w0 + cb * w1 + cc * w2, trimesh.cpp:179-189.
+struct alignas(8) TriColor {
+  double ca[3], cb[3], cc[3];
+};
+
 // One material texture: 8-bit RGB, row 0 = bottom row.
 struct TexRec {
   const uint8_t *data;
@@ -75,6 +82,8 @@ struct alignas(8) ObjRec {
   int32_t material;
   int32_t smooth;  // mesh has per-vertex normals
   int32_t has_uv;  // mesh has per-vertex UV coordinates
+  int32_t has_colors;  // mesh has per-vertex colours and no UV coordinates (trimesh.cpp:170-189)
+  int32_t pad;
 };
 
 // Material record as shadeBRDF reads it (material.cpp:88-109).  Scalars already

@@ -602,6 +602,7 @@ int build_host_scene(const mipt_scene_desc *d, HostScene *out, std::string *err,
         return fail(MIPT_ERR_INVALID, "bad mesh arrays");
       o.smooth = m.normals ? 1 : 0;
       o.has_uv = m.uvs ? 1 : 0;
+      o.has_colors = (m.colors && !m.uvs) ? 1 : 0;
       if (m.n_vertices == 0) have = false;
       else {
         mn = mx = D3{m.vertices[0], m.vertices[1], m.vertices[2]};  // trimesh.h:75-90
@@ -635,10 +636,12 @@ int build_host_scene(const mipt_scene_desc *d, HostScene *out, std::string *err,
   std::vector<TriNormals> normsRef;  // by reference-order index (if any smooth mesh)
   std::vector<uint32_t> infoRef;
   std::vector<TriUV> uvsRef;         // by reference-order index (if any mesh has UV coordinates)
-  bool anySmooth = false, anyUV = false;
+  std::vector<TriColor> colorsRef;   // by reference-order index (if any mesh shades with vertex colours)
+  bool anySmooth = false, anyUV = false, anyColor = false;
   for (size_t k = 0; k < nObj; k++) {
     if (S.objects[k].smooth) anySmooth = true;
     if (S.objects[k].has_uv) anyUV = true;
+    if (S.objects[k].has_colors) anyColor = true;
   }
 
   for (size_t ord = 0; ord < nObj; ord++) {
@@ -659,6 +662,7 @@ int build_host_scene(const mipt_scene_desc *d, HostScene *out, std::string *err,
       trisRef.push_back(t);
       if (anySmooth) { TriNormals tn; std::memset(&tn, 0, sizeof(tn)); normsRef.push_back(tn); }
       if (anyUV) uvsRef.push_back(TriUV{0, 0, 0, 0, 0, 0});
+      if (anyColor) { TriColor tc; std::memset(&tc, 0, sizeof(tc)); colorsRef.push_back(tc); }
       infoRef.push_back(make_prim_info((uint32_t)src.type, oi));
       continue;
     }
@@ -693,6 +697,7 @@ int build_host_scene(const mipt_scene_desc *d, HostScene *out, std::string *err,
     trisRef.resize(base + nf);
     if (anySmooth) normsRef.resize(base + nf);
     if (anyUV) uvsRef.resize(base + nf);
+    if (anyColor) colorsRef.resize(base + nf);
     infoRef.resize(base + nf);
     auto do_faces = [&](size_t q0, size_t q1) {
     for (size_t q = q0; q < q1; q++) {
@@ -740,6 +745,17 @@ int build_host_scene(const mipt_scene_desc *d, HostScene *out, std::string *err,
         if (m.uvs) tu = TriUV{m.uvs[2 * ia], m.uvs[2 * ia + 1], m.uvs[2 * ib], m.uvs[2 * ib + 1], m.uvs[2 * ic], m.uvs[2 * ic + 1]};
         uvsRef[base + q] = tu;
       }
+      if (anyColor) {
+        TriColor tc;
+        std::memset(&tc, 0, sizeof(tc));
+        if (o.has_colors)
+          for (int ch = 0; ch < 3; ch++) {
+            tc.ca[ch] = m.colors[3 * ia + ch];
+            tc.cb[ch] = m.colors[3 * ib + ch];
+            tc.cc[ch] = m.colors[3 * ic + ch];
+          }
+        colorsRef[base + q] = tc;
+      }
       infoRef[base + q] = make_prim_info(KIND_TRI, oi);
     }
     };
@@ -763,6 +779,7 @@ int build_host_scene(const mipt_scene_desc *d, HostScene *out, std::string *err,
     S.prim_info = std::move(infoRef);
     if (anySmooth) S.tri_normals = std::move(normsRef);
     if (anyUV) S.tri_uvs = std::move(uvsRef);
+    if (anyColor) S.tri_colors = std::move(colorsRef);
     S.ref_order.resize(nPrims);
     S.prim_boxes.resize(6 * nPrims);
     for (size_t s = 0; s < nPrims; s++) {
@@ -836,6 +853,7 @@ int build_host_scene(const mipt_scene_desc *d, HostScene *out, std::string *err,
   S.ref_order.resize(nPrims);
   if (anySmooth) S.tri_normals.resize(nPrims);
   if (anyUV) S.tri_uvs.resize(nPrims);
+  if (anyColor) S.tri_colors.resize(nPrims);
   for (size_t s = 0; s < nPrims; s++) {
     uint32_t id = prims[s].id;
     S.tris[s] = trisRef[id];
@@ -843,6 +861,7 @@ int build_host_scene(const mipt_scene_desc *d, HostScene *out, std::string *err,
     S.ref_order[s] = id;
     if (anySmooth) S.tri_normals[s] = normsRef[id];
     if (anyUV) S.tri_uvs[s] = uvsRef[id];
+    if (anyColor) S.tri_colors[s] = colorsRef[id];
   }
   timer.lap("leaf-order arrays");
   }

@@ -18,6 +18,7 @@ struct HostScene {
   std::vector<Tri> tris;               // per primitive (leaf order); unused slots for analytic prims
   std::vector<TriNormals> tri_normals; // per primitive, empty if no mesh has vertex normals
   std::vector<TriUV> tri_uvs;          // per primitive, empty if no mesh has UV coordinates
+  std::vector<TriColor> tri_colors;    // per primitive, empty if no mesh shades with vertex colours
   std::vector<uint32_t> prim_info;     // kind << 30 | object
   int n_analytic = 0;                  // primitives [0, n_analytic) are spheres/boxes/squares, the rest triangles
   std::vector<uint32_t> ref_order;     // reference visiting order of each primitive (tie-break key)

@@ -11,7 +11,7 @@ shadeBRDF reads through a texture, diffuse and ambient; mapped specular / reflec
 emissive / normal are parsed and dropped like the constants of those keys (shadeBRDF never
 reads them), a mapped transmissive is refused.
 
-Out of scope (raises): cylinder / cone (no path-tracer scene uses them), obj_mesh.
+Out of scope (raises): cylinder / cone (no path-tracer scene uses them).
 """
 from __future__ import annotations
 
@@ -59,6 +59,7 @@ class MeshRec:
     faces: np.ndarray  # (m, 3) int32
     normals: Optional[np.ndarray] = None  # (n, 3) float64
     uvs: Optional[np.ndarray] = None  # (n, 2) float64
+    colors: Optional[np.ndarray] = None  # (n, 3) float64, read only when uvs is None (trimesh.cpp:170-189)
 
 
 @dataclass
@@ -159,6 +160,10 @@ class Scene:
                 uv = np.ascontiguousarray(m.uvs, dtype=np.float64)
                 keep.append(uv)
                 meshes[k].uvs = uv.ctypes.data_as(C.POINTER(C.c_double))
+            if m.colors is not None:
+                col = np.ascontiguousarray(m.colors, dtype=np.float64)
+                keep.append(col)
+                meshes[k].colors = col.ctypes.data_as(C.POINTER(C.c_double))
         lights = (abi.Light * max(1, len(self.lights)))()
         for k, L in enumerate(self.lights):
             lights[k].type = int(L.type)
@@ -218,6 +223,8 @@ class Scene:
                 arrs[f"mesh{k}_n"] = m.normals
             if m.uvs is not None:
                 arrs[f"mesh{k}_uv"] = m.uvs
+            if m.colors is not None:
+                arrs[f"mesh{k}_c"] = m.colors
         for k, t in enumerate(self.textures):
             arrs[f"texture{k}"] = t
         if self.cubemap is not None:
@@ -243,7 +250,8 @@ class Scene:
         for k in range(int(z["n_meshes"][0])):
             n = z[f"mesh{k}_n"] if f"mesh{k}_n" in z.files else None
             uv = z[f"mesh{k}_uv"] if f"mesh{k}_uv" in z.files else None
-            s.meshes.append(MeshRec(z[f"mesh{k}_v"], z[f"mesh{k}_f"], n, uv))
+            col = z[f"mesh{k}_c"] if f"mesh{k}_c" in z.files else None
+            s.meshes.append(MeshRec(z[f"mesh{k}_v"], z[f"mesh{k}_f"], n, uv, col))
         k = 0
         while f"texture{k}" in z.files:
             s.textures.append(z[f"texture{k}"])
@@ -390,7 +398,9 @@ class _Parser:
             self.scene.objects.append(ObjectRec(t, self.material_index(val), -1, xf))
         elif key == "tri_mesh":
             self.parse_trimesh(val, xf)
-        elif key in ("cylinder", "cone", "obj_mesh"):
+        elif key == "obj_mesh":
+            self.parse_objmesh(val, xf)
+        elif key in ("cylinder", "cone"):
             raise NotImplementedError(f"{key} is out of scope of the path-tracing hot path")
         else:
             raise SceneFormatError("Unknown geometry type: " + key)
@@ -428,6 +438,36 @@ class _Parser:
             normals = generate_normals(verts, faces, normals)
         self.scene.meshes.append(MeshRec(verts, faces, normals, uvs))
         self.scene.objects.append(ObjectRec(abi.OBJ_TRIMESH, mat, len(self.scene.meshes) - 1, xf))
+
+    def parse_objmesh(self, j, xf):  # JsonParser.cpp:692-754 and loadObjToTrimesh, :556-690
+        from . import objfile
+
+        path = os.path.join(self.scene_dir, str(j["objfile"]))
+        try:
+            data = objfile.read_obj(path, self.scene_dir)
+        except (OSError, objfile.ObjFormatError) as e:
+            raise SceneFormatError(f"Error while parsing OBJ file: {e}") from e
+        for shape in data.shapes:
+            try:
+                verts, faces, normals, uvs, colors = objfile.shape_to_mesh(data, shape)
+            except objfile.ObjFormatError as e:
+                raise SceneFormatError(str(e)) from e
+            # a fresh Material, then the FIRST material of the library (:650-674); the scene's
+            # current material is not inherited
+            m = MaterialRec()
+            if data.materials:
+                mtl = data.materials[0]
+                m.kd, m.ka, m.kt = mtl.diffuse.copy(), mtl.ambient.copy(), mtl.transmittance.copy()
+                m.index = float(mtl.ior)
+                if mtl.diffuse_texname:
+                    m.kd_texture = self.texture_index(mtl.diffuse_texname)
+                if mtl.specular_texname:
+                    load_image(os.path.join(self.scene_dir, mtl.specular_texname))  # loaded, never read by shadeBRDF
+            self.scene.materials.append(m)
+            if j.get("gennormals") is True:
+                normals = generate_normals(verts, faces, normals)
+            self.scene.meshes.append(MeshRec(verts, faces, normals, uvs, colors))
+            self.scene.objects.append(ObjectRec(abi.OBJ_TRIMESH, len(self.scene.materials) - 1, len(self.scene.meshes) - 1, xf))
 
     def parse_transform(self, obj):  # JsonParser.cpp:384-445
         key, val = next(iter(obj.items()))
