@@ -37,6 +37,11 @@ int main(int argc, char **argv) {
         for (long long k = 0; k < 2 * m.n_vertices; k++) std::printf(" %.17g", m.uvs[k]);
         std::printf("\n");
       }
+      if (m.colors) {
+        std::printf("color");
+        for (long long k = 0; k < 3 * m.n_vertices; k++) std::printf(" %.17g", m.colors[k]);
+        std::printf("\n");
+      }
     }
     for (int i = 0; i < d.n_textures; i++) {
       const mipt_image &t = d.textures[i];

@@ -1,5 +1,7 @@
 #include "scene_loader.h"
 
+#include "obj_reader.h"
+
 #include <cmath>
 #include <cstring>
 #include <fstream>
@@ -242,6 +244,46 @@ struct Parser {
     addObject(MIPT_OBJ_TRIMESH, mat, (int)scene.meshes.size() - 1);
   }
 
+  // parseObjmeshBody + loadObjToTrimesh, JsonParser.cpp:556-754: one Trimesh per shape,
+  // each with a fresh Material filled from the FIRST material of the OBJ's library (the
+  // scene's current material is not inherited).
+  void parseObjmesh(const Json &j) {
+    std::string path = scene_dir + "/" + j.at("objfile").str;
+    bool gen = false;
+    try { if (j.has("gennormals")) gen = j.at("gennormals").boolean(); } catch (const JsonError &) {}
+    try {
+      ObjData data = read_obj(path, scene_dir);
+      for (const ObjShape &shape : data.shapes) {
+        ObjMesh om = obj_shape_to_mesh(data, shape);
+        mipt_material m = default_material();
+        if (!data.materials.empty()) {
+          const ObjMaterial &mtl = data.materials[0];
+          for (int k = 0; k < 3; k++) { m.kd[k] = mtl.diffuse[k]; m.ka[k] = mtl.ambient[k]; m.kt[k] = mtl.transmittance[k]; }
+          m.index = mtl.ior;
+          if (!mtl.diffuse_texname.empty()) m.kd_texture = textureIndex(mtl.diffuse_texname);
+          if (!mtl.specular_texname.empty()) textureFileCheck(mtl.specular_texname);  // loaded by the reference, never read by shadeBRDF
+        }
+        scene.materials.push_back(m);
+        MeshData mesh;
+        mesh.vertices = std::move(om.vertices);
+        mesh.faces = std::move(om.faces);
+        mesh.normals = std::move(om.normals);
+        mesh.uvs = std::move(om.uvs);
+        mesh.colors = std::move(om.colors);
+        if (gen) generateNormals(&mesh);
+        scene.meshes.push_back(std::move(mesh));
+        addObject(MIPT_OBJ_TRIMESH, (int)scene.materials.size() - 1, (int)scene.meshes.size() - 1);
+      }
+    } catch (const ObjError &e) {
+      throw SceneError(std::string("Error while parsing OBJ file: ") + e.what());
+    }
+  }
+
+  void textureFileCheck(const std::string &name) {
+    std::ifstream f(scene_dir + "/" + name, std::ios::binary);
+    if (!f) throw SceneError("Unable to load texture map '" + scene_dir + "/" + name + "'.");
+  }
+
   // Trimesh::generateNormals, trimesh.cpp:204-231.
   static void generateNormals(MeshData *mesh) {
     size_t nv = mesh->vertices.size() / 3;
@@ -278,7 +320,8 @@ struct Parser {
     else if (key == "box") addObject(MIPT_OBJ_BOX, materialIndex(val), -1);
     else if (key == "square") addObject(MIPT_OBJ_SQUARE, materialIndex(val), -1);
     else if (key == "tri_mesh") parseTrimesh(val);
-    else if (key == "cylinder" || key == "cone" || key == "obj_mesh") throw SceneError(key + " is outside the path-tracing hot path and not supported by this host");
+    else if (key == "obj_mesh") parseObjmesh(val);
+    else if (key == "cylinder" || key == "cone") throw SceneError(key + " is outside the path-tracing hot path and not supported by this host");
     else throw SceneError("Unknown geometry type: " + key);
   }
 
@@ -404,6 +447,7 @@ mipt_scene_desc SceneData::describe() {
     v.n_faces = (int64_t)(m.faces.size() / 3);
     v.normals = m.normals.empty() ? nullptr : m.normals.data();
     v.uvs = m.uvs.empty() ? nullptr : m.uvs.data();
+    v.colors = m.colors.empty() ? nullptr : m.colors.data();
     mesh_views_.push_back(v);
   }
   d.meshes = mesh_views_.data();

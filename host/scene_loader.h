@@ -47,6 +47,7 @@ struct MeshData {
   std::vector<int32_t> faces;
   std::vector<double> normals;
   std::vector<double> uvs;  // 2 per vertex, or empty (the "UV" key)
+  std::vector<double> colors;  // 3 per vertex, or empty (OBJ files with "v x y z r g b" only)
 };
 
 struct SceneData {

@@ -240,10 +240,9 @@ def cornell_area_light(scene: Scene) -> Scene:
 
 
 def tessellate_boxes(scene: Scene) -> Scene:
-    """A copy of `scene` with every Box replaced by a 12-triangle mesh of the same surface, its
-    vertices already in world space the way the scene reader stores mesh vertices
-    (JsonParser.cpp:253-262).  Mirroring transforms get their winding flipped so the face
-    normals (trimesh.cpp:102-107) keep pointing out of the box."""
+    """A copy of `scene` with every Box replaced by a 12-triangle mesh of the same surface:
+    vertices in world space under an identity transform.  Mirroring transforms get their
+    winding flipped so the face normals (trimesh.h:145-146) keep pointing out of the box."""
     import copy
 
     out = copy.deepcopy(scene)

@@ -65,6 +65,8 @@ def parse_dump(text):
             out.setdefault("mattex", []).append((int(tok[1]), int(tok[2])))
         elif tok[0] == "uv":
             out.setdefault("uvs", []).append(np.array(tok[1:], float))
+        elif tok[0] == "color":
+            out.setdefault("colors", []).append(np.array(tok[1:], float))
         elif tok[0] == "texture":
             out.setdefault("textures", []).append([int(x) for x in tok[1:]])
         elif tok[0] == "light":
@@ -118,6 +120,45 @@ def test_cpp_loader_reads_uvs_and_ppm_textures(host_bins, tmp_path):
     path.write_text(json.dumps(scene))
     r = subprocess.run([os.path.join(host_bins, "dump_scene"), str(path)], capture_output=True)
     assert r.returncode == 2 and b"Unable to load texture map" in r.stderr
+
+
+def test_cpp_loader_reads_obj_meshes_like_the_python_loader(host_bins, tmp_path):
+    from tests.test_objmesh import CUBE_OBJ
+
+    tex = np.random.RandomState(7).randint(0, 256, size=(2, 3, 3)).astype(np.uint8)
+    with open(tmp_path / "wood grain.ppm", "wb") as fh:
+        fh.write(b"P6\n3 2\n255\n" + tex.tobytes())
+    (tmp_path / "things.obj").write_text(CUBE_OBJ)
+    (tmp_path / "things.mtl").write_text("newmtl first\nKd 0.35 0.5 0.75\nKa 0.1 0.1 0.1\nTf 0.2 0 0\nNi 1.5\nmap_Kd -clamp on wood grain.ppm\nnewmtl second\nKd 1 0 0\n")
+    # a second file with normals and texture coordinates, smooth normals regenerated on top
+    (tmp_path / "fan.obj").write_text("v 0 0 0\nv 1 0 0.125\nv 1 1 0\nv 0 1 0.35\nvn 0 0 2\nvt 0.25 0.75\nvt 1 0\nf 1/1/1 2/2/1 3/1/1 4/2/1\n")
+    scene = [
+        {"camera": {"position": [0.5, 0.5, 5], "viewdir": [0, 0, -1], "updir": [0, 1, 0]}},
+        {"material": {"diffuse": {"constant": [0.9, 0.9, 0.9]}}},
+        {"translate": [[0, 0, -1], [{"obj_mesh": {"objfile": "things.obj"}}]]},
+        {"obj_mesh": {"objfile": "fan.obj", "gennormals": True}},
+    ]
+    path = tmp_path / "scene.json"
+    path.write_text(json.dumps(scene))
+    d = parse_dump(subprocess.check_output([os.path.join(host_bins, "dump_scene"), str(path)]).decode())
+    sc = load_json_scene(str(path))
+    assert len(d["meshes"]) == len(sc.meshes) == 3 and len(d["objects"]) == 3
+    for (v, f, n), pm in zip(d["meshes"], sc.meshes):
+        assert np.array_equal(v, pm.vertices.ravel()) and np.array_equal(f, pm.faces.ravel())  # the same doubles, bit for bit
+        assert (n is None) == (pm.normals is None)
+        if n is not None:
+            assert np.allclose(n, pm.normals.ravel(), rtol=1e-15, atol=0)
+    assert len(d["colors"]) == 2 and all(np.array_equal(c, pm.colors.ravel()) for c, pm in zip(d["colors"], sc.meshes[:2]))
+    assert sc.meshes[2].colors is None and len(d["uvs"]) == 1 and np.array_equal(d["uvs"][0], sc.meshes[2].uvs.ravel())
+    for (t, mesh, xf, mat), o in zip(d["objects"], sc.objects):
+        m = sc.materials[o.material]
+        assert np.array_equal(mat, np.concatenate([m.kd, m.ka, m.kt, [m.roughness, m.metallic, m.index]]))
+    assert d["mattex"] == [(m.kd_texture, m.ka_texture) for m in (sc.materials[o.material] for o in sc.objects)] == [(1, 0), (1, 0), (0, 0)]
+    assert len(d["textures"]) == 1 and d["textures"][0][:2] == [3, 2]
+    # errors carry the reference's prefix
+    (tmp_path / "fan.obj").write_text("v 0 0 0\nf 0 1 1\n")
+    r = subprocess.run([os.path.join(host_bins, "dump_scene"), str(path)], capture_output=True)
+    assert r.returncode == 2 and b"Error while parsing OBJ file" in r.stderr
 
 
 def test_cpp_loader_reports_errors(host_bins, tmp_path):
