@@ -50,6 +50,26 @@ __global__ void __launch_bounds__(256, 6) gather_w(const float4 *__restrict__ no
   out[tid] = acc + (float)idx;
 }
 
+// Cooperative form: the four lanes of a quad follow one chain and each loads its own 16-byte
+// quarter of the 64-byte record (NCH chains per quad and step = NCH loads per lane).
+template <int NCH>
+__global__ void __launch_bounds__(256, 6) gather_quad(const float4 *__restrict__ nodes, uint32_t mask, int steps, float *out) {
+  uint32_t tid = blockIdx.x * 256 + threadIdx.x;
+  uint32_t idx[NCH];
+  for (int c = 0; c < NCH; c++) idx[c] = ((tid / 4) * NCH + c) * 2654435761u + 12345u;
+  float acc = 0.f;
+  for (int s = 0; s < steps; s++) {
+    float4 a[NCH];
+    for (int c = 0; c < NCH; c++) a[c] = nodes[(size_t)(idx[c] & mask) * 4 + (tid & 3)];
+    for (int c = 0; c < NCH; c++) {
+      acc += a[c].x;
+      idx[c] = idx[c] * 1664525u + 1013904223u + (__float_as_uint(a[c].w) & 0u);
+      idx[c] ^= idx[c] >> 15;
+    }
+  }
+  out[tid] = acc + (float)idx[0];
+}
+
 // LDS gather: every lane reads NL x 16 bytes of a random 64-byte record held in LDS.
 template <int NL>
 __global__ void __launch_bounds__(256, 6) gather_lds(int records, int steps, float *out) {
@@ -126,6 +146,9 @@ int main() {
 #define RUNW(W, G) printf("  one %2d-byte load, %3d lanes per address (negative: strided over the wave): %6.1f cycles per wave-step per CU\n", W, G, \
     time_cycles([&](int st) { hipLaunchKernelGGL((gather_w<W, G>), dim3(grid), dim3(256), 0, 0, d, mask, st, out); }, 2000, mhz));
   RUNW(16, 1) RUNW(8, 1) RUNW(4, 1) RUNW(16, 2) RUNW(16, 4) RUNW(16, 16) RUNW(16, 64) RUNW(16, -2) RUNW(16, -4) RUNW(16, -16)
+#define RUNQ(NCH) printf("  quad-cooperative fetch of %d records per quad and step (64 B each, 16 B per lane): %6.1f cycles per wave-step per CU\n", NCH, \
+    time_cycles([&](int st) { hipLaunchKernelGGL((gather_quad<NCH>), dim3(grid), dim3(256), 0, 0, d, mask, st, out); }, 2000, mhz));
+  RUNQ(1) RUNQ(4)
 #define RUNL(NL) printf("  LDS gather, %d x16B of a 64-byte record (320 records): %6.1f cycles per wave-step per CU\n", NL, \
     time_cycles([&](int st) { hipLaunchKernelGGL((gather_lds<NL>), dim3(grid), dim3(256), 320 * 64, 0, 320, st, out); }, 2000, mhz));
   RUNL(1) RUNL(2) RUNL(4)
