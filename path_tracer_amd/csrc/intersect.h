@@ -133,17 +133,22 @@ __device__ __forceinline__ bool analytic_hit(const ObjRec *o, uint32_t kind, d3 
 
 // TrimeshFace::intersectLocal, trimesh.cpp:98-200, on the world-space triangle.
 // w1/w2 are the barycentric weights of the second and third vertex.
-__device__ __forceinline__ bool tri_hit(const Tri *tr, d3 org, d3 dir, double &t, double &w1, double &w2) {
-  d3 n = ld3(tr->n);
+// `tfar`: hits beyond it do not matter to the caller (the walk's current best); they are
+// rejected before the barycentric half of the record is fetched.
+__device__ __forceinline__ bool tri_hit(const Tri *tr, d3 org, d3 dir, double &t, double &w1, double &w2, double tfar = 1.0e300) {
+  const double2 *w = reinterpret_cast<const double2 *>(tr);
+  const double2 w0 = w[0], w1_ = w[1], w2_ = w[2];  // one round trip for the plane
+  d3 n{w0.x, w0.y, w1_.x};
   double denom = dot(n, dir);
   if (fabs(denom) < MIPT_RAY_EPSILON) return false;
-  d3 a = ld3(tr->a);
+  d3 a{w1_.y, w2_.x, w2_.y};
   double num = dot(a - org, n);
   double tt = num / denom;
-  if (!(tt >= 0)) return false;
+  if (!(tt >= 0) || tt > tfar) return false;
+  const double2 w3 = w[3], w4 = w[4], w5 = w[5];  // a second one for the edges
   d3 pa = (org + tt * dir) - a;
-  double b1 = dot(pa, ld3(tr->q1));
-  double b2 = dot(pa, ld3(tr->q2));
+  double b1 = dot(pa, d3{w3.x, w3.y, w4.x});
+  double b2 = dot(pa, d3{w4.y, w5.x, w5.y});
   double b0 = 1 - b1 - b2;
   if (!(b0 >= 0 && b0 <= 1 && b1 >= 0 && b1 <= 1 && b2 >= 0 && b2 <= 1)) return false;
   t = tt;
@@ -299,7 +304,7 @@ __device__ __forceinline__ bool prim_test(Trav &T, const SceneDev &S, uint32_t s
   bool hit;
   if (s >= (uint32_t)S.n_analytic) {
     double w1, w2;
-    hit = tri_hit(S.tris + s, T.org, T.dir, t, w1, w2);
+    hit = tri_hit(S.tris + s, T.org, T.dir, t, w1, w2, T.best.t);
   } else {
     uint32_t info = S.prim_info[s];
     d3 Nl;

@@ -39,9 +39,11 @@ static_assert(sizeof(Node4) == 64, "Node4 must be 64 bytes");
 //        (normalize(normalMatrix * cross(b-a, c-a)), trimesh.h:145-146, scene.h:92-94)
 //   q1, q2 : dual edge vectors, beta = (P-a).q1, gamma = (P-a).q2 — the inverse Gram
 //        matrix of trimesh.h:152-157 folded into the edges
+// The plane (n, a) fills the first three 16-byte words, the edge vectors the last three:
+// a test fetches the first half, and the second only if the plane is hit within range.
 struct alignas(16) Tri {
-  double a[3];
   double n[3];
+  double a[3];
   double q1[3];
   double q2[3];
 };
