@@ -181,6 +181,18 @@ __global__ void __launch_bounds__(kBlock) k_generate(SceneDev S, RenderConst rc,
 constexpr uint32_t kRefillIdle = MIPT_REFILL_IDLE;                  // shadow rays
 constexpr uint32_t kRefillIdleClosest = MIPT_REFILL_IDLE_CLOSEST;  // path rays
 
+// Workgroups go to the eight XCDs round-robin (block b runs on XCD b % 8), and every XCD has
+// an L2 of its own.  Numbering the blocks XCD-major makes the waves of one XCD take
+// neighbouring chunks of the item sequence at any moment, so an XCD's L2 holds the part of
+// the scene its rays are in rather than a share of everything.
+#ifndef MIPT_XCD_MAJOR
+#define MIPT_XCD_MAJOR 1
+#endif
+__device__ __forceinline__ uint32_t xcd_major_block() {
+  if (!MIPT_XCD_MAJOR || (gridDim.x & 7u) != 0u) return blockIdx.x;
+  return (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+}
+
 __device__ __forceinline__ uint64_t wave_seq_item(uint32_t i, uint32_t wave, uint32_t n_waves) {
   return ((uint64_t)(i >> 6) * n_waves + wave) * 64ull + (i & 63u);
 }
@@ -197,7 +209,7 @@ __global__ void __launch_bounds__(kBlock, MIPT_TRAV_WAVES) k_intersect(SceneDev 
   extern __shared__ uint32_t lds_stack[];
   const Stack stack{lds_stack + threadIdx.x, kBlock, blockIdx.x * kBlock + threadIdx.x};
   const uint32_t lane = lane_id();
-  const uint32_t wave = blockIdx.x * (kBlock / 64) + threadIdx.x / 64;
+  const uint32_t wave = xcd_major_block() * (kBlock / 64) + threadIdx.x / 64;
   const uint32_t n_waves = gridDim.x * (kBlock / 64);
   TravCounters tc{0, 0};
   Trav T;
@@ -506,7 +518,7 @@ __global__ void __launch_bounds__(kBlock, MIPT_TRAV_WAVES) k_shadow_any(SceneDev
   extern __shared__ uint32_t lds_stack[];
   const Stack stack{lds_stack + threadIdx.x, kBlock, blockIdx.x * kBlock + threadIdx.x};
   const uint32_t lane = lane_id();
-  const uint32_t wave = blockIdx.x * (kBlock / 64) + threadIdx.x / 64;
+  const uint32_t wave = xcd_major_block() * (kBlock / 64) + threadIdx.x / 64;
   const uint32_t n_waves = gridDim.x * (kBlock / 64);
   const uint32_t R = (uint32_t)S.rays_per_hit;
   TravCounters tc{0, 0};
