@@ -133,6 +133,67 @@ bool read_mtl(const std::string &path, std::vector<ObjMaterial> *out) {  // tiny
   return true;
 }
 
+// Crossing-number test of (tx, ty) against a triangle, tiny_obj_loader.h:1557-1569.
+bool inside_triangle(const double vx[3], const double vy[3], double tx, double ty) {
+  bool c = false;
+  for (int i = 0, j = 2; i < 3; j = i++)
+    if (((vy[i] > ty) != (vy[j] > ty)) && (tx < (vx[j] - vx[i]) * (ty - vy[i]) / (vy[j] - vy[i]) + vx[i])) c = !c;
+  return c;
+}
+
+// Polygons with five or more corners, cut the way the reference's loader does it (built-in
+// ear clipping, tiny_obj_loader.h:1886-2132), quirks included: projection on two axes chosen
+// from the first non-degenerate corner, a convexity test that multiplies the corner's cross
+// product by (x0 * y1 - y0 * x1) / 2 of its first two points, and a walk that gives up after
+// a full turn without an ear (what is left is dropped unless it is a triangle).
+void ear_clip(const std::vector<ObjCorner> &face, const std::vector<double> &v, std::vector<ObjCorner> *out) {
+  const size_t n = face.size();
+  const double eps = 2.220446049250313e-16;
+  int axes[2] = {1, 2};
+  for (size_t k = 0; k < n; k++) {
+    const double *p0 = &v[3 * (size_t)face[k % n].v], *p1 = &v[3 * (size_t)face[(k + 1) % n].v], *p2 = &v[3 * (size_t)face[(k + 2) % n].v];
+    double e0[3], e1[3];
+    for (int a = 0; a < 3; a++) { e0[a] = p1[a] - p0[a]; e1[a] = p2[a] - p1[a]; }
+    double cx = std::fabs(e0[1] * e1[2] - e0[2] * e1[1]);
+    double cy = std::fabs(e0[2] * e1[0] - e0[0] * e1[2]);
+    double cz = std::fabs(e0[0] * e1[1] - e0[1] * e1[0]);
+    if (cx > eps || cy > eps || cz > eps) {
+      if (!(cx > cy && cx > cz)) {
+        axes[0] = 0;
+        if (cz > cx && cz > cy) axes[1] = 1;
+      }
+      break;
+    }
+  }
+  std::vector<ObjCorner> rest = face;
+  size_t guess = 0, budget = n, before = n;
+  while (rest.size() > 3 && budget > 0) {
+    const size_t m = rest.size();
+    if (guess >= m) guess -= m;
+    if (before != m) { before = m; budget = m; }
+    else budget--;
+    ObjCorner tri[3];
+    double vx[3], vy[3];
+    for (int k = 0; k < 3; k++) {
+      tri[k] = rest[(guess + k) % m];
+      vx[k] = v[3 * (size_t)tri[k].v + axes[0]];
+      vy[k] = v[3 * (size_t)tri[k].v + axes[1]];
+    }
+    double cross = (vx[1] - vx[0]) * (vy[2] - vy[1]) - (vy[1] - vy[0]) * (vx[2] - vx[1]);
+    double area = (vx[0] * vy[1] - vy[0] * vx[1]) * 0.5;
+    if (cross * area < 0.0) { guess++; continue; }
+    bool overlap = false;
+    for (size_t other = 3; other < m && !overlap; other++) {
+      const double *q = &v[3 * (size_t)rest[(guess + other) % m].v];
+      overlap = inside_triangle(vx, vy, q[axes[0]], q[axes[1]]);
+    }
+    if (overlap) { guess++; continue; }
+    out->insert(out->end(), tri, tri + 3);
+    rest.erase(rest.begin() + (long)((guess + 1) % m));
+  }
+  if (rest.size() == 3) out->insert(out->end(), rest.begin(), rest.end());
+}
+
 }  // namespace
 
 bool obj_parse_double(const std::string &tok, double *out) {  // tiny_obj_loader.h:915-1083
@@ -217,7 +278,9 @@ ObjData read_obj(const std::string &path, const std::string &mtl_dir) {  // tiny
         const int *order = s02 < s13 ? near02 : near13;
         for (int k = 0; k < 6; k++) shape.corners.push_back(f[order[k]]);
       } else {
-        throw ObjError(path + ": faces with more than four corners are not supported");
+        for (const ObjCorner &c : f)
+          if (c.v < 0 || (size_t)(3 * c.v + 2) >= data.vertices.size()) throw ObjError(path + ": vertex index out of range in a polygon");
+        ear_clip(f, data.vertices, &shape.corners);
       }
     }
     faces.clear();

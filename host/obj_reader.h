@@ -7,7 +7,8 @@
 //     3*0.1 + 5*0.01, not the correctly rounded double);
 //   * v [r g b], vn, vt, f with i, i/j, i//k, i/j/k corners and relative indices; `g` / `o`
 //     start a new shape, `usemtl` does not; colours only if every vertex has them;
-//   * quads cut along the shorter diagonal (:1642-1743); larger polygons are refused;
+//   * quads cut along the shorter diagonal (:1642-1743), larger polygons by the loader's
+//     built-in ear clipping (:1886-2132);
 //   * MTL: newmtl, Ka, Kd, Ks, Kt/Tf, Ke, Ns, Ni, map_Kd, map_Ks.
 #ifndef MIPT_HOST_OBJ_READER_H_
 #define MIPT_HOST_OBJ_READER_H_

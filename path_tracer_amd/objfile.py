@@ -13,8 +13,8 @@ pipeline a scene can observe:
 * `v x y z [r g b]`, `vn`, `vt`, `f` with i, i/j, i//k, i/j/k corners and negative (relative)
   indices, `g` / `o` start a new shape, `usemtl` does not (tiny_obj_loader.h:2910-3314);
   colours are kept only if every vertex has them (:2917-2928, :3424-3427);
-* quads are cut along the shorter diagonal (:1642-1743); faces with more than four corners
-  are refused here (the reference ear-clips them, :1886 on: not restated);
+* quads are cut along the shorter diagonal (:1642-1743), larger polygons by the loader's
+  built-in ear clipping (:1886-2132), quirks included;
 * MTL: newmtl, Ka, Kd, Ks, Kt/Tf, Ke, Ns, Ni, map_Kd, map_Ks (:2326-2575); the mesh takes
   the FIRST material of the library, whatever `usemtl` says (JsonParser.cpp:650-674).
 """
@@ -237,6 +237,78 @@ def _corner(tok: str, nv: int, nvn: int, nvt: int) -> Tuple[int, int, int]:
     return v, vt, vn
 
 
+def _inside(vx, vy, tx, ty) -> bool:
+    """Crossing-number test of (tx, ty) against the triangle (vx, vy), tiny_obj_loader.h:1557-1569."""
+    c = False
+    j = 2
+    for i in range(3):
+        if (vy[i] > ty) != (vy[j] > ty) and tx < (vx[j] - vx[i]) * (ty - vy[i]) / (vy[j] - vy[i]) + vx[i]:
+            c = not c
+        j = i
+    return c
+
+
+def ear_clip(face: List[Tuple[int, int, int]], vertices) -> List[Tuple[int, int, int]]:
+    """Triangles of a polygon with five or more corners the way the reference's loader cuts
+    them (its built-in ear clipping, tiny_obj_loader.h:1886-2132), quirks included: the
+    polygon is projected on the two axes chosen from its first non-degenerate corner, the
+    convexity test multiplies the corner's cross product by (x0 * y1 - y0 * x1) / 2 of the
+    corner's first two points, and the walk gives up after a full turn without an ear (what
+    is left is dropped unless it is a triangle)."""
+    n = len(face)
+    eps = 2.220446049250313e-16
+    axes = [1, 2]
+    for k in range(n):
+        p0, p1, p2 = (vertices[face[(k + d) % n][0]] for d in range(3))
+        e0 = [p1[a] - p0[a] for a in range(3)]
+        e1 = [p2[a] - p1[a] for a in range(3)]
+        cx = abs(e0[1] * e1[2] - e0[2] * e1[1])
+        cy = abs(e0[2] * e1[0] - e0[0] * e1[2])
+        cz = abs(e0[0] * e1[1] - e0[1] * e1[0])
+        if cx > eps or cy > eps or cz > eps:
+            if not (cx > cy and cx > cz):
+                axes[0] = 0
+                if cz > cx and cz > cy:
+                    axes[1] = 1
+            break
+    rest = list(face)
+    out: List[Tuple[int, int, int]] = []
+    guess = 0
+    budget = n
+    before = n
+    while len(rest) > 3 and budget > 0:
+        m = len(rest)
+        if guess >= m:
+            guess -= m
+        if before != m:
+            before = m
+            budget = m
+        else:
+            budget -= 1
+        tri = [rest[(guess + k) % m] for k in range(3)]
+        vx = [vertices[c[0]][axes[0]] for c in tri]
+        vy = [vertices[c[0]][axes[1]] for c in tri]
+        cross = (vx[1] - vx[0]) * (vy[2] - vy[1]) - (vy[1] - vy[0]) * (vx[2] - vx[1])
+        area = (vx[0] * vy[1] - vy[0] * vx[1]) * 0.5
+        if cross * area < 0.0:
+            guess += 1
+            continue
+        overlap = False
+        for other in range(3, m):
+            q = vertices[rest[(guess + other) % m][0]]
+            if _inside(vx, vy, q[axes[0]], q[axes[1]]):
+                overlap = True
+                break
+        if overlap:
+            guess += 1
+            continue
+        out.extend(tri)
+        del rest[(guess + 1) % m]
+    if len(rest) == 3:
+        out.extend(rest)
+    return out
+
+
 def read_obj(path: str, mtl_dir: Optional[str] = None) -> ObjData:
     """Parse `path`; material libraries are looked up in `mtl_dir` (the scene's directory,
     JsonParser.cpp:702), falling back to default materials when none loads."""
@@ -268,7 +340,10 @@ def read_obj(path: str, mtl_dir: Optional[str] = None) -> ObjData:
                     order = (0, 1, 2, 0, 2, 3) if s02 < s13 else (0, 1, 3, 1, 2, 3)
                     shape.corners.extend(f[k] for k in order)
             else:
-                raise ObjFormatError(f"{path}: faces with more than four corners are not supported")
+                for c in f:
+                    if not 0 <= c[0] < len(data.vertices):
+                        raise ObjFormatError(f"{path}: vertex index out of range in a polygon")
+                shape.corners.extend(ear_clip(f, data.vertices))
         faces.clear()
 
     def end_shape(name: str):

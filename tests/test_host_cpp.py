@@ -131,7 +131,8 @@ def test_cpp_loader_reads_obj_meshes_like_the_python_loader(host_bins, tmp_path)
     (tmp_path / "things.obj").write_text(CUBE_OBJ)
     (tmp_path / "things.mtl").write_text("newmtl first\nKd 0.35 0.5 0.75\nKa 0.1 0.1 0.1\nTf 0.2 0 0\nNi 1.5\nmap_Kd -clamp on wood grain.ppm\nnewmtl second\nKd 1 0 0\n")
     # a second file with normals and texture coordinates, smooth normals regenerated on top
-    (tmp_path / "fan.obj").write_text("v 0 0 0\nv 1 0 0.125\nv 1 1 0\nv 0 1 0.35\nvn 0 0 2\nvt 0.25 0.75\nvt 1 0\nf 1/1/1 2/2/1 3/1/1 4/2/1\n")
+    (tmp_path / "fan.obj").write_text("v 0 0 0\nv 1 0 0.125\nv 1 1 0\nv 0 1 0.35\nv 1 1 1\nv 3 1 1\nv 3 2 1\nv 2 2 1\nv 2 3 1\nv 1 3 1\n"
+                                        "vn 0 0 2\nvt 0.25 0.75\nvt 1 0\nf 1/1/1 2/2/1 3/1/1 4/2/1\nf 5/1/1 6/1/1 7/1/1 8/1/1 9/1/1 10/1/1\n")
     scene = [
         {"camera": {"position": [0.5, 0.5, 5], "viewdir": [0, 0, -1], "updir": [0, 1, 0]}},
         {"material": {"diffuse": {"constant": [0.9, 0.9, 0.9]}}},

@@ -125,10 +125,26 @@ f 1 2 3 4
     assert m.colors is None
     # |v2 - v0|^2 = 5 < |v3 - v1|^2 = 10 -> (0,1,2), (0,2,3)
     assert m.faces.tolist() == [[0, 1, 2], [0, 2, 3]]
-    with pytest.raises(SceneFormatError, match="more than four"):
-        write_scene(tmp_path, obj + "v 0 2 0\nf 1 2 3 4 5\n", None)
+    with pytest.raises(SceneFormatError, match="out of range"):
+        write_scene(tmp_path, obj + "v 0 2 0\nf 1 2 3 4 9\n", None)
     with pytest.raises(SceneFormatError, match="zero value"):
         write_scene(tmp_path, obj + "f 0 1 2\n", None)
+
+
+def test_polygons_are_ear_clipped_like_the_reference_loader(tmp_path):
+    # an L-shaped hexagon, counter-clockwise.  Worked by hand through tiny_obj_loader.h:1886-2132:
+    # corner (0,1,2) fails the sign test (cross 2, "area" (1*1 - 1*3)/2 = -1), (1,2,3) is the
+    # first ear, then (3,4,5), (3,5,0), and (0,1,3) is what remains.
+    obj = "v 1 1 0\nv 3 1 0\nv 3 2 0\nv 2 2 0\nv 2 3 0\nv 1 3 0\nf 1 2 3 4 5 6\n"
+    sc = write_scene(tmp_path, obj, None)
+    (m,) = sc.meshes
+    order = [1, 2, 3, 4, 5, 0]  # mesh vertex k is OBJ vertex order[k] (numbered by first use)
+    tris = [[order[i] for i in f] for f in m.faces.tolist()]
+    assert tris == [[1, 2, 3], [3, 4, 5], [3, 5, 0], [0, 1, 3]]
+    # a convex pentagon becomes a fan around its first corner
+    pts = [(math.cos(2 * math.pi * k / 5) + 2, math.sin(2 * math.pi * k / 5) + 2, 0.0) for k in range(5)]
+    clipped = objfile.ear_clip([(k, -1, -1) for k in range(5)], pts)
+    assert [c[0] for c in clipped] == [0, 1, 2, 0, 2, 3, 0, 3, 4]
 
 
 def test_texture_names_and_gennormals(tmp_path):
