@@ -120,9 +120,10 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="synth1m", choices=sorted(list(WORKLOADS) + list(FIXTURE_WORKLOADS)))
-    ap.add_argument("--spp-per-step", type=int, default=64)
+    ap.add_argument("--spp-per-step", type=int, default=0,
+                    help="samples per pixel in one step; 0 = as many as the free HBM allows (128, 64 or 16 at 1080p)")
     ap.add_argument("--triangles", type=int, default=0)
-    ap.add_argument("--batch-samples", type=int, default=1 << 27)
+    ap.add_argument("--batch-samples", type=int, default=0, help="samples per wavefront batch; 0 = one batch per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -159,9 +160,25 @@ def main():
     upload_s = time.time() - t0
     stats = ctx.scene_stats()
 
-    K, W, S = args.steps, args.warmup, args.spp_per_step
+    # One step = one batch.  The deep, nearly empty levels of a batch cost the same ~16 ms
+    # whatever its size, so the batch is as large as the free HBM allows (about 700 B per
+    # sample with the shadow-ray scratch); every rank takes the smallest choice of any rank.
+    S = args.spp_per_step
+    if S <= 0:
+        free_b = torch.cuda.mem_get_info(local_rank)[0]
+        if world > 1:
+            t = torch.tensor([free_b], dtype=torch.int64, device=f"cuda:{local_rank}" if args.backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            free_b = int(t.item())
+        S = 1
+        for cand in (128, 64, 32, 16, 8, 4, 2):
+            if cand * w * h * 700 + (40 << 30) <= free_b and cand * w * h <= (1 << 28):
+                S = cand
+                break
+    batch = args.batch_samples if args.batch_samples > 0 else min(1 << 28, max(1 << 20, S * w * h))
+    K, W = args.steps, args.warmup
     total_spp = world * (K + W) * S  # the job the steps are slices of
-    base = abi.default_params(w, h, spp=total_spp, batch_samples=args.batch_samples)
+    base = abi.default_params(w, h, spp=total_spp, batch_samples=batch)
     d_sum = torch.zeros(3 * w * h, dtype=torch.float64, device=f"cuda:{local_rank}")
     stream = torch.cuda.current_stream().cuda_stream
 
@@ -246,6 +263,7 @@ def main():
             "config": {
                 "workload": label,
                 "spp_per_step": S,
+                "batch_samples": int(batch),
                 "nominal_spp": nominal_spp,
                 "rr_q": base.rr_q,
                 "area_samples": base.area_samples,
