@@ -137,7 +137,7 @@ struct BuildPrim {
 
 constexpr int kLeafMax = 2;    // preferred leaf size (wide quantised nodes make small leaves pay)
 constexpr int kLeafHard = 8;   // encoding limit (3 bits)
-constexpr int kBins = 16;
+constexpr int kBins = 32;
 
 // Binary node of the SAH build, before the collapse to four-wide nodes.
 struct BinNode {
