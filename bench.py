@@ -126,6 +126,9 @@ def main():
     ap.add_argument("--batch-samples", type=int, default=0, help="samples per wavefront batch; 0 = one batch per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
+    ap.add_argument("--cull-negligible", action="store_true",
+                    help="set MIPT_FLAG_CULL_NEGLIGIBLE: skip shadow rays whose whole term is below 2^-52 (off: every shadow "
+                         "ray the reference traces is traced)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo rehearses the N>1 path with several ranks on one GPU (RCCL needs one GPU per rank)")
     args = ap.parse_args()
@@ -182,11 +185,13 @@ def main():
     d_sum = torch.zeros(3 * w * h, dtype=torch.float64, device=f"cuda:{local_rank}")
     stream = torch.cuda.current_stream().cuda_stream
 
+    extra_flags = abi.FLAG_CULL_NEGLIGIBLE if args.cull_negligible else 0
+
     def step_params(step, flags):
         p = shard_params(base, rank, world, "samples")
         first = p.sample_begin + step * S
         p.sample_begin, p.sample_end = first, first + S
-        p.flags = flags
+        p.flags = flags | extra_flags
         return p
 
     def sync():
@@ -272,6 +277,7 @@ def main():
                 "bvh_nodes": stats["nodes"],
                 "scene_bytes": stats["device_bytes"],
                 "sharding": "samples" if world > 1 else "none",
+                "cull_negligible": bool(args.cull_negligible),
             },
             "roofline": roofline,
             "kernel_ms_per_step": {k: v["ms"] / K for k, v in ktimes.items()},

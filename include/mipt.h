@@ -160,6 +160,16 @@ typedef struct mipt_scene_desc {
                                            events on its stream and accumulate
                                            the durations (mipt_get_kernel_times) */
 
+#define MIPT_FLAG_CULL_NEGLIGIBLE 8u    /* off by default: do not trace the shadow
+                                           rays of a hit whose whole direct-diffuse
+                                           term is bounded below 2^-52 (throughput *
+                                           kd / pi * (1 - metallic) * sum of light
+                                           colours).  The reference traces them: a
+                                           "metallic 1" material reads back as
+                                           0.9999999999999999 (material.cpp:232-241)
+                                           and keeps a diffuse weight of 1.1e-16.
+                                           Changes a sample by < 1e-15            */
+
 /* The literals of the reference are parameters here and default to the
  * reference's values (mipt_default_params):
  *   spp 100 (RayTracer.cpp:61), rr_q 0.1 (RayTracer.cpp:229,277),

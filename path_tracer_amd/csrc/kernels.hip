@@ -332,8 +332,10 @@ __global__ void __launch_bounds__(kShadeBlock) k_shade(SceneDev S, RenderConst r
         double norm = (1.0 - rc.rr_q) * (mirror ? 2.0 : 1.0);
         // terms that need no shadow ray: ambient + direct specular, material.cpp:96,132-143
         d3 A = ka * ld3(S.ambient);
+        double lsum = 0.0;  // sum over lights of the brightest colour channel
         for (int li = 0; li < S.n_lights; li++) {
           const LightRec &L = S.lights[li];
+          lsum += fmax(fabs(L.color[0]), fmax(fabs(L.color[1]), fabs(L.color[2])));
           d3 Ld = light_direction(L, P);
           d3 H = normalize(Ld + V);
           d3 F = pow5v(F0, 1 - fabs(dot(V, H)));
@@ -361,6 +363,13 @@ __global__ void __launch_bounds__(kShadeBlock) k_shade(SceneDev S, RenderConst r
         emitMirror = deeper && mirror;
         rdir = d - N * dot(N, d) * 2.0;  // glm::reflect, RayTracer.cpp:270
         emitShade = S.n_lights > 0 && (W.x != 0.0 || W.y != 0.0 || W.z != 0.0);
+        if (emitShade && (rc.flags & MIPT_FLAG_CULL_NEGLIGIBLE)) {
+          // every shadow ray of this hit only scales a term bounded by max|W| * sum of the
+          // lights' brightest channels (attenuations and |n.L| are <= 1); below 2^-52 it
+          // cannot move a sample, which lives in [0, 1], by one unit in the last place of 1
+          double wmax = fmax(fabs(W.x), fmax(fabs(W.y), fabs(W.z)));
+          emitShade = !(wmax * lsum < 2.220446049250313e-16);
+        }
       }
     }
   }

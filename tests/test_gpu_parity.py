@@ -254,6 +254,32 @@ def test_mesh_scene_images(gpu, oracle_lib):
     assert_images_match(f32, ref, rgb8, ref8, frac=0.995)
 
 
+def test_cull_negligible_flag_skips_rays_without_changing_the_image(gpu, oracle_lib):
+    """MIPT_FLAG_CULL_NEGLIGIBLE drops the shadow rays of hits on "metallic 1" materials (diffuse
+    weight 1.1e-16 after material.cpp:232-241) and nothing else: fewer shadow rays, the same
+    path trees, an image within 1e-14 of the full one and still on the oracle's."""
+    from path_tracer_amd import synth
+
+    sc = synth.make_scene(20000, seed=7)
+    upload(gpu, sc)
+    imgs, cnts = [], []
+    for extra in (0, abi.FLAG_CULL_NEGLIGIBLE):
+        gpu.reset_counters()
+        p = abi.default_params(128, 72, spp=4, flags=abi.FLAG_COUNTERS | extra)
+        f32, _ = gpu.render(p, want_rgb8=False)
+        imgs.append(f32.astype(np.float64))
+        cnts.append(gpu.counters())
+    full, culled = cnts
+    assert culled["shadow_rays"] < full["shadow_rays"]
+    assert culled["shadow_rays"] > 0.5 * full["shadow_rays"]
+    for k in ("samples", "path_rays", "shaded_hits"):
+        assert culled[k] == full[k]
+    assert np.abs(imgs[0] - imgs[1]).max() <= 1e-7  # fp32 output: at most one rounding apart
+    assert (imgs[0] != imgs[1]).mean() < 1e-3
+    ref = oracle_lib.Oracle(sc).render(abi.default_params(128, 72, spp=4), threads=8)
+    assert np.abs(imgs[1] - ref).max() <= 1e-5
+
+
 @pytest.mark.parametrize("variant", ["cornell_area_light", "hitchcock_tessellated"])
 def test_authored_variants_of_the_demo_scenes(variant, gpu, oracle_lib, scenes):
     """cornellBoxes under a rectangular area light (10 shadow rays per hit) and hitchcockBRDF
