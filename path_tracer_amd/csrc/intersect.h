@@ -161,7 +161,7 @@ __device__ __forceinline__ bool tri_hit(const Tri *tr, d3 org, d3 dir, double &t
 // A plane at coordinate b is crossed at t = b * id + off, with off lowered (near planes)
 // or raised (far planes) by pad = 2^-21 * (R + |o|) * |1/d|: more than the error of
 // rounding the origin and the reciprocal to fp32 and of evaluating b * id in two fmas
-// (trav_round).  Axis-parallel rays use |d| = 1e-30.
+// (node_test).  Axis-parallel rays use |d| = 1e-30.
 struct Cull {
   float idx, idy, idz;
   float nx, ny, nz;  // near-plane offsets
@@ -263,13 +263,16 @@ __device__ __forceinline__ float ubyte_f(uint32_t w, int k) { return (float)((w 
     int cc_ = ch[a]; ch[a] = ch[b]; ch[b] = cc_;                \
   }
 
-// The children of inner node `node` the ray can enter: ch[k] = child reference, t[k] = entry
-// distance, or 3e38 where the ray misses the child's box or the child is absent.
+// The children of inner node `node` the ray can enter: ch[k] = child reference, hit[k] = the
+// ray meets the child's box, and (NEED_T) t[k] = entry distance, 3e38 for a missed or absent child.
 // The ray is moved into the node's quantised frame once (per axis
 // t = q * (step / d) + ((origin - o) / d -+ pad)), then each child costs six byte->float
-// conversions and six fmas.  The error of the extra fma stays inside the pad of make_cull
-// (about 2 of its 8 units of 2^-24 (R + |o|) |1/d| are used).
-__device__ __forceinline__ void node_test(const Trav &T, const SceneDev &S, int node, int ch[4], float t[4]) {
+// conversions and six fmas.  The errors stay inside the pad of make_cull: in units of
+// 2^-24 (R + |o|) |1/d|, of which the pad holds 8, the rounded reciprocal costs one and each
+// of the two chained fmas one (|t| of a plane never exceeds (R + |o|) |1/d| by more than the
+// 1 % the quantised root box may stick out), so near and far values can be compared as they are.
+template <bool NEED_T>
+__device__ __forceinline__ void node_test(const Trav &T, const SceneDev &S, int node, int ch[4], float t[4], bool hit[4]) {
   const uint4 *np = reinterpret_cast<const uint4 *>(S.nodes + node);
   uint4 q0 = np[0], q1 = np[1], q2 = np[2];
   int4 q3 = *reinterpret_cast<const int4 *>(np + 3);
@@ -291,8 +294,8 @@ __device__ __forceinline__ void node_test(const Trav &T, const SceneDev &S, int 
                      fmaxf(__fmaf_rn(ubyte_f(nZ, k), az, bnz), 0.0f));
     float tf = fminf(fminf(__fmaf_rn(ubyte_f(fX, k), ax, bfx), __fmaf_rn(ubyte_f(fY, k), ay, bfy)),
                      fminf(__fmaf_rn(ubyte_f(fZ, k), az, bfz), T.tlimit));
-    // one rounding of the last fma is left on each side: a relative 2^-22 slack covers it
-    t[k] = (tn <= tf * 1.0000005f && ch[k] != kNoChild) ? tn : 3.0e38f;
+    hit[k] = tn <= tf && ch[k] != kNoChild;  // tf <= tlimit is finite, so an overflowed tn misses
+    if (NEED_T) t[k] = hit[k] ? tn : 3.0e38f;
   }
 }
 
@@ -331,21 +334,23 @@ template <bool ANY, bool COUNT>
 __device__ __forceinline__ void trav_round(Trav &T, const SceneDev &S, const Stack &stk, TravCounters &tc) {
   int cur = T.cur, sp = T.sp;
   while (cur >= 0) {
+    // any-hit walks do not sort: nearest-first saves 2 % of their node visits, the sort costs more
+    constexpr bool SORTED = !ANY;
     int ch[4];
     float t[4];
-    node_test(T, S, cur, ch, t);
+    bool hit[4];
+    node_test<SORTED>(T, S, cur, ch, t, hit);
 #ifdef MIPT_LANE_STATS  // lane slots instead of visits: 64 per wave-level iteration
     if (COUNT) { unsigned long long m_ = __ballot(1); if (__lane_id() == (unsigned)__ffsll((long long)m_) - 1u) tc.nodes += 64; }
 #else
     if (COUNT) tc.nodes++;
 #endif
-    // any-hit walks do not sort: nearest-first saves 2 % of their node visits, the sort costs more
-    constexpr bool SORTED = !ANY;
     if (SORTED) {
       MIPT_CSWAP(0, 1) MIPT_CSWAP(2, 3) MIPT_CSWAP(0, 2) MIPT_CSWAP(1, 3) MIPT_CSWAP(1, 2)
     }
     // enter the first child that was hit, stack the others so that they pop in order
-    const bool h0 = t[0] < 2.0e38f, h1 = t[1] < 2.0e38f, h2 = t[2] < 2.0e38f, h3 = t[3] < 2.0e38f;
+    const bool h0 = SORTED ? t[0] < 2.0e38f : hit[0], h1 = SORTED ? t[1] < 2.0e38f : hit[1];
+    const bool h2 = SORTED ? t[2] < 2.0e38f : hit[2], h3 = SORTED ? t[3] < 2.0e38f : hit[3];
     // sorted (closest hit): the hits are the first entries, so child k >= 1 is stacked iff hit
     const bool p1 = !SORTED ? (h1 && h0) : h1;
     const bool p2 = !SORTED ? (h2 && (h0 || h1)) : h2;
