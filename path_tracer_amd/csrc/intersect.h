@@ -356,13 +356,15 @@ __device__ __forceinline__ void trav_round(Trav &T, const SceneDev &S, const Sta
     const bool p2 = !SORTED ? (h2 && (h0 || h1)) : h2;
     const bool p3 = !SORTED ? (h3 && (h0 || h1 || h2)) : h3;
     const int enter = h0 ? ch[0] : h1 ? ch[1] : h2 ? ch[2] : ch[3];
-    if (sp + 3 <= S.stack_entries) {  // all in LDS: three predicated writes, no inner branches
-      if (p3) stk.lds[sp * stk.stride] = (uint32_t)ch[3];
-      const int s2 = sp + (p3 ? 1 : 0);
-      if (p2) stk.lds[s2 * stk.stride] = (uint32_t)ch[2];
-      const int s1 = s2 + (p2 ? 1 : 0);
-      if (p1) stk.lds[s1 * stk.stride] = (uint32_t)ch[1];
-      sp = s1 + (p1 ? 1 : 0);
+    if (sp + 3 <= S.stack_entries) {
+      // all in LDS: three unconditional writes; one that is not to be kept lands above the
+      // top of the stack and is overwritten by the next (no exec-mask changes, no branches)
+      stk.lds[sp * stk.stride] = (uint32_t)ch[3];
+      sp += p3 ? 1 : 0;
+      stk.lds[sp * stk.stride] = (uint32_t)ch[2];
+      sp += p2 ? 1 : 0;
+      stk.lds[sp * stk.stride] = (uint32_t)ch[1];
+      sp += p1 ? 1 : 0;
     } else {
       if (p3) stack_push(S, stk, sp, (uint32_t)ch[3]);
       if (p2) stack_push(S, stk, sp, (uint32_t)ch[2]);
