@@ -505,6 +505,16 @@ int mipt_render_accumulate(mipt_ctx *c, const mipt_params *p, double *d_sum, voi
   if ((r = sync_lights(c, p->area_samples)) != MIPT_OK) return r;
   bool count = (p->flags & MIPT_FLAG_COUNTERS) != 0;
   bool prof = (p->flags & MIPT_FLAG_PROFILE) != 0;
+  // a call that fails half way leaves no half-recorded event pairs behind
+  struct SpanGuard {
+    mipt_ctx *c;
+    bool done = false;
+    ~SpanGuard() {
+      if (done) return;
+      c->spans.clear();
+      c->events_used = 0;
+    }
+  } span_guard{c};
 
   // rows owned by this shard
   std::vector<int> rows;
@@ -626,6 +636,7 @@ int mipt_render_accumulate(mipt_ctx *c, const mipt_params *p, double *d_sum, voi
   }
   HIP_TRY(c, hipStreamSynchronize(st));
   if (prof) collect_spans(c);
+  span_guard.done = true;
   HIP_TRY(c, hipGetLastError());
   return MIPT_OK;
 }
