@@ -48,7 +48,8 @@ def _mesh(rng, n_faces, smooth):
     return MeshRec(v, f, normals)
 
 
-def random_scene(seed):
+def random_scene(seed, big_mesh=0):
+    """big_mesh > 0: one more mesh of that many faces (enough primitives for the device builder)."""
     rng = np.random.RandomState(seed)
     translucent = seed % 3 == 0
     spread = 2.5
@@ -58,6 +59,9 @@ def random_scene(seed):
     for _ in range(rng.randint(0, 3)):
         meshes.append(_mesh(rng, int(rng.choice([1, 2, 7, 40, 300])), smooth=bool(rng.rand() < 0.5)))
         objs.append((abi.OBJ_TRIMESH, _xform(rng, spread), _material(rng, translucent), len(meshes) - 1))
+    if big_mesh:
+        meshes.append(_mesh(rng, big_mesh, smooth=bool(seed % 2)))
+        objs.append((abi.OBJ_TRIMESH, U.scale(2.0), _material(rng, False), len(meshes) - 1))
     # a floor so that most camera rays end somewhere
     objs.append((abi.OBJ_SQUARE, U.translate(0, -3.5, 0) @ U.rot_x(-math.pi / 2) @ U.scale(40), _material(rng, False)))
     lights = []
@@ -72,16 +76,34 @@ def random_scene(seed):
             lights.append(U.area_light(rng.uniform(-2, 2, 3) + np.array([0, 6.0, 0]), (1, 0, 0), (0, 0, 1), float(rng.uniform(0.5, 3)),
                                        float(rng.uniform(0.5, 3)), color=rng.uniform(0.3, 1.0, 3), atten=(1.0, 0.0, float(rng.uniform(0, 0.02)))))
     cam = U.camera(eye=(0.3, 1.0, 9.0), viewdir=(0.0, -0.15, -1.0), fov=50.0)
-    return U.scene(objs, lights=lights, cam=cam, ambient=rng.uniform(0, 0.2, 3), meshes=meshes)
+    cubemap = None
+    if seed % 4 == 1:
+        from path_tracer_amd import synth
+
+        cubemap = synth.make_sky_cubemap(16)
+    return U.scene(objs, lights=lights, cam=cam, ambient=rng.uniform(0, 0.2, 3), meshes=meshes, cubemap=cubemap)
 
 
-@pytest.mark.parametrize("seed", list(range(1, 13)))
+@pytest.mark.parametrize("seed", list(range(1, 33)))
 def test_random_scene_matches_the_oracle(seed, gpu, oracle_lib):
-    sc = random_scene(seed)
+    check_scene(random_scene(seed), seed, gpu, oracle_lib)
+
+
+@pytest.mark.parametrize("builder", ["host", "gpu"])
+@pytest.mark.parametrize("seed", [101, 102, 103])
+def test_random_scene_with_a_large_triangle_soup(seed, builder, gpu, oracle_lib, monkeypatch):
+    """6000 random triangles piercing one another (long thin overlapping boxes: the worst case for
+    a BVH), through the host builder and through the device builder."""
+    if builder == "gpu":
+        monkeypatch.setenv("MIPT_BUILDER", "gpu")
+    check_scene(random_scene(seed, big_mesh=6000), seed, gpu, oracle_lib, n_rays=3000, n_fire=10, frame=None)
+
+
+def check_scene(sc, seed, gpu, oracle_lib, n_rays=6000, n_fire=100000, frame=(80, 60)):
     orc = oracle_lib.Oracle(sc)
     gpu.upload_scene(sc)
     # --- closest hits: camera rays, then bounce-style rays from the hit points
-    org, d = U.camera_rays(sc, 6000, seed=seed)
+    org, d = U.camera_rays(sc, n_rays, seed=seed)
     tg, pg, ng = gpu.intersect(org, d)
     to, po, no = orc.intersect(org, d)
     same = pg == po
@@ -99,7 +121,7 @@ def test_random_scene_matches_the_oracle(seed, gpu, oracle_lib):
     h2 = same2 & (po2 >= 0)
     assert np.all(np.abs(tg2[h2] - to2[h2]) <= 1e-9 * np.maximum(1.0, to2[h2]))
     # --- shadow attenuation of every light from the hit points (any-hit or the occluder walk)
-    fire = P + no[hit] * 3e-8
+    fire = (P + no[hit] * 3e-8)[:n_fire]
     keys = np.arange(len(fire), dtype=np.uint64) * np.uint64(2654435761) + np.uint64(seed)
     p = abi.default_params(8, 8)
     for li in range(len(sc.lights)):
@@ -109,7 +131,10 @@ def test_random_scene_matches_the_oracle(seed, gpu, oracle_lib):
         assert bad.mean() <= 3e-3, f"light {li}: {bad.sum()} of {len(fire)} shading points differ"
     # --- frames: deterministic 1 spp, then the reference's settings with shared random streams (depth capped: random
     # mirrors among random triangles make path trees that grow by half per level, in the reference without end)
-    for prm in (abi.default_params(80, 60, spp=1, rr_q=0.0, max_depth=4, flags=abi.FLAG_FIXED_AREA_PATTERN), abi.default_params(48, 36, spp=4, max_depth=6)):
+    if frame is None:  # the oracle's literal occluder walks through a dense soup take seconds per ray
+        return
+    for prm in (abi.default_params(frame[0], frame[1], spp=1, rr_q=0.0, max_depth=4, flags=abi.FLAG_FIXED_AREA_PATTERN),
+                abi.default_params(frame[0] // 2, frame[1] // 2, spp=4, max_depth=6)):
         f32, _ = gpu.render(prm, want_rgb8=False)
         ref = orc.render(prm, threads=8)
         diff = np.abs(f32.astype(np.float64) - ref).max(axis=2)
