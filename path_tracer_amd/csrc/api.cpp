@@ -44,6 +44,7 @@ struct mipt_ctx {
   uint32_t capacity = 0;
   DevBuf queue[2], shade, hits, accum, rows, counts, dcount;
   DevBuf vis;                // per-shadow-ray results of one chunk of hits
+  DevBuf ray_light;          // light index of every shadow ray of a hit
   int n_cus = 256;
   int persist_blocks = 1536; // CUs x blocks per CU for the persistent traversal kernels
   DevBuf spill;              // overflow stack of ray records (allocated on first use)
@@ -250,6 +251,15 @@ int sync_lights(mipt_ctx *c, int area_samples) {
     first += L.samples;
   }
   c->dev.rays_per_hit = first;
+  {
+    std::vector<uint16_t> table((size_t)std::max(first, 1));
+    for (size_t k = 0; k < c->lights_host.size(); k++)
+      for (int s = 0; s < c->lights_host[k].samples; s++) table[(size_t)(c->lights_host[k].first_ray + s)] = (uint16_t)k;
+    int r = ensure(c, c->ray_light, table.size() * sizeof(uint16_t));
+    if (r != MIPT_OK) return r;
+    HIP_TRY(c, hipMemcpy(c->ray_light.p, table.data(), table.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    c->dev.ray_light = reinterpret_cast<const uint16_t *>(c->ray_light.p);
+  }
   if (!c->lights_host.empty())
     HIP_TRY(c, hipMemcpy(const_cast<LightRec *>(c->dev.lights), c->lights_host.data(), c->lights_host.size() * sizeof(LightRec), hipMemcpyHostToDevice));
   c->lights_area_samples = area_samples;
@@ -316,6 +326,7 @@ void mipt_destroy(mipt_ctx *c) {
   release(c->dcount);
   release(c->spill);
   release(c->vis);
+  release(c->ray_light);
   for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
   delete c;
 }
@@ -440,6 +451,8 @@ int mipt_upload_scene(mipt_ctx *c, const mipt_scene_desc *desc) {
   if ((r = upload(c, H.materials, &D.materials)) != MIPT_OK) return r;
   if ((r = upload(c, H.lights, &D.lights)) != MIPT_OK) return r;
   D.n_lights = (int)H.lights.size();
+  if (D.n_lights > 65535) return set_err(c, MIPT_ERR_LIMIT, "more than 65535 lights");
+  D.ray_light = nullptr;  // filled by sync_lights once area_samples is known
   D.n_materials = (int)H.materials.size();
   D.n_prims = (int)H.prim_info.size();
   D.n_analytic = H.n_analytic;

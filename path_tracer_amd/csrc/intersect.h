@@ -32,6 +32,7 @@ struct SceneDev {
   const ObjRec *objects;
   const MatRec *materials;
   const LightRec *lights;
+  const uint16_t *ray_light;  // light of every shadow ray of a hit (rays_per_hit entries)
   int n_lights;
   int n_materials;
   int n_prims;

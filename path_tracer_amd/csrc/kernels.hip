@@ -511,6 +511,7 @@ __device__ d3 shadow_ray(const SceneDev &S, const RenderConst &rc, const LightRe
 
 // Shadow ray `r` of a hit belongs to the light whose block of rays contains it.
 __device__ __forceinline__ int light_of_ray(const SceneDev &S, uint32_t r) {
+  if (S.n_lights > 4) return (int)S.ray_light[r];  // many lights: a table, one cached load
   int li = 0;
   for (int k = 1; k < S.n_lights; k++)
     if ((uint32_t)S.lights[k].first_ray <= r) li = k;

@@ -48,8 +48,9 @@ def _mesh(rng, n_faces, smooth):
     return MeshRec(v, f, normals)
 
 
-def random_scene(seed, big_mesh=0):
-    """big_mesh > 0: one more mesh of that many faces (enough primitives for the device builder)."""
+def random_scene(seed, big_mesh=0, n_lights=0):
+    """big_mesh > 0: one more mesh of that many faces (enough primitives for the device builder);
+    n_lights > 0: that many lights of random kinds instead of one to three."""
     rng = np.random.RandomState(seed)
     translucent = seed % 3 == 0
     spread = 2.5
@@ -65,7 +66,7 @@ def random_scene(seed, big_mesh=0):
     # a floor so that most camera rays end somewhere
     objs.append((abi.OBJ_SQUARE, U.translate(0, -3.5, 0) @ U.rot_x(-math.pi / 2) @ U.scale(40), _material(rng, False)))
     lights = []
-    kinds = rng.permutation(3)[: rng.randint(1, 4)]
+    kinds = rng.permutation(3)[: rng.randint(1, 4)] if not n_lights else rng.randint(0, 3, size=n_lights)
     for k in kinds:
         if k == 0:
             lights.append(U.dir_light(rng.normal(size=3) + np.array([0, -2.0, 0]), color=rng.uniform(0.3, 1.0, 3)))
@@ -97,6 +98,13 @@ def test_random_scene_with_a_large_triangle_soup(seed, builder, gpu, oracle_lib,
     if builder == "gpu":
         monkeypatch.setenv("MIPT_BUILDER", "gpu")
     check_scene(random_scene(seed, big_mesh=6000), seed, gpu, oracle_lib, n_rays=3000, n_fire=10, frame=None)
+
+
+@pytest.mark.parametrize("seed", [201, 202, 203])
+def test_random_scene_with_many_lights(seed, gpu, oracle_lib):
+    """Seven and twelve lights of mixed kinds: with more than four the kernels find a shadow ray's
+    light in a table instead of scanning the light list."""
+    check_scene(random_scene(seed, n_lights=7 if seed != 203 else 12), seed, gpu, oracle_lib, n_rays=3000, n_fire=600, frame=(48, 36))
 
 
 def check_scene(sc, seed, gpu, oracle_lib, n_rays=6000, n_fire=100000, frame=(80, 60)):
