@@ -639,6 +639,44 @@ __global__ void __launch_bounds__(kBlock) k_shadow_sum(SceneDev S, ShadeList sl,
   deposit(accum, sl.slot[h], total);
 }
 
+// The same sum for scenes with many lights, one lane per (hit, light): a lane-per-hit loop walks
+// rays_per_hit doubles at a stride of rays_per_hit doubles between lanes, which wastes most of
+// every cache line when there are hundreds of rays per hit.  Here adjacent lanes read adjacent
+// runs of `samples` doubles, evaluate their light once, and the lanes of one hit (adjacent, a
+// run may straddle waves) are added with a segmented shuffle reduction before the deposit.
+__global__ void __launch_bounds__(kBlock) k_shadow_sum_lights(SceneDev S, ShadeList sl, uint32_t first_hit, uint32_t n_hits,
+                                                               const double *__restrict__ vis, double *accum) {
+  const uint64_t item = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  const uint32_t nL = (uint32_t)S.n_lights;
+  const bool live = item < (uint64_t)n_hits * nL;
+  const uint32_t i = live ? (uint32_t)(item / nL) : 0xffffffffu;  // hit within this launch
+  const uint32_t h = first_hit + (live ? i : 0u);
+  d3 c{0, 0, 0};
+  if (live) {
+    const uint32_t li = (uint32_t)(item - (uint64_t)i * nL);
+    const LightRec &L = S.lights[li];
+    const double *v = vis + (uint64_t)i * (uint32_t)S.rays_per_hit + (uint32_t)L.first_ray;
+    double sum = 0.0;
+    for (int s = 0; s < L.samples; s++) sum += v[s];
+    d3 col = ld3(L.color) * sum;
+    if (L.type == MIPT_LIGHT_RECT_AREA) col = col / (double)L.samples;  // light.cpp:145
+    d3 P{sl.px[h], sl.py[h], sl.pz[h]};
+    d3 N{sl.nx[h], sl.ny[h], sl.nz[h]};
+    d3 Wt{sl.wx[h], sl.wy[h], sl.wz[h]};
+    double f = distance_attenuation(L, P) * fabs(dot(N, light_direction(L, P)));
+    c = (col * f) * Wt;
+  }
+  const uint32_t lane = lane_id();
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t oi = (uint32_t)__shfl_down((int)i, off);
+    const double ox = __shfl_down(c.x, off), oy = __shfl_down(c.y, off), oz = __shfl_down(c.z, off);
+    if (lane + (uint32_t)off < 64u && oi == i) c = c + d3{ox, oy, oz};
+  }
+  const uint32_t pi = (uint32_t)__shfl_up((int)i, 1);
+  if (live && (lane == 0u || pi != i)) deposit(accum, sl.slot[h], c);
+}
+
 // ----------------------------------------------------------------- resolve ----
 __global__ void __launch_bounds__(kBlock) k_resolve(RenderConst rc, const double *__restrict__ accum, const int *__restrict__ rows,
                                                      int64_t first_pixel, int n_pixels, int n_samples, double *d_sum, DeviceCounters *dc) {
@@ -826,6 +864,11 @@ void launch_shadow_trace(const SceneDev &S, const RenderConst &rc, ShadeList sl,
 
 void launch_shadow_sum(const SceneDev &S, ShadeList sl, uint64_t first_hit, uint32_t n_hits, const double *vis, double *accum, hipStream_t st) {
   if (!n_hits || !S.rays_per_hit) return;
+  if (!S.translucent && S.n_lights > 4) {
+    hipLaunchKernelGGL(k_shadow_sum_lights, dim3(grid_for((uint64_t)n_hits * (uint64_t)S.n_lights)), dim3(kBlock), 0, st, S, sl, (uint32_t)first_hit,
+                       n_hits, vis, accum);
+    return;
+  }
   auto kern = S.translucent ? k_shadow_sum<true> : k_shadow_sum<false>;
   hipLaunchKernelGGL(kern, dim3(grid_for(n_hits)), dim3(kBlock), 0, st, S, sl, (uint32_t)first_hit, n_hits, vis, accum);
 }
