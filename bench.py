@@ -129,6 +129,9 @@ def main():
     ap.add_argument("--cull-negligible", action="store_true",
                     help="set MIPT_FLAG_CULL_NEGLIGIBLE: skip shadow rays whose whole term is below 2^-52 (off: every shadow "
                          "ray the reference traces is traced)")
+    ap.add_argument("--sharding", default="samples", choices=["samples", "tiles"],
+                    help="N > 1: 'samples' = every rank renders the whole frame for its own samples (weak scaling, reduce); "
+                         "'tiles' = every rank renders all samples of its own bands of rows (strong scaling, gather)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo rehearses the N>1 path with several ranks on one GPU (RCCL needs one GPU per rank)")
     args = ap.parse_args()
@@ -180,7 +183,8 @@ def main():
                 break
     batch = args.batch_samples if args.batch_samples > 0 else min(1 << 28, max(1 << 20, S * w * h))
     K, W = args.steps, args.warmup
-    total_spp = world * (K + W) * S  # the job the steps are slices of
+    tiles = args.sharding == "tiles" and world > 1
+    total_spp = (1 if tiles else world) * (K + W) * S  # the job the steps are slices of
     base = abi.default_params(w, h, spp=total_spp, batch_samples=batch)
     d_sum = torch.zeros(3 * w * h, dtype=torch.float64, device=f"cuda:{local_rank}")
     stream = torch.cuda.current_stream().cuda_stream
@@ -188,7 +192,7 @@ def main():
     extra_flags = abi.FLAG_CULL_NEGLIGIBLE if args.cull_negligible else 0
 
     def step_params(step, flags):
-        p = shard_params(base, rank, world, "samples")
+        p = shard_params(base, rank, world, "tiles" if tiles else "samples")
         first = p.sample_begin + step * S
         p.sample_begin, p.sample_end = first, first + S
         p.flags = flags | extra_flags
@@ -204,13 +208,13 @@ def main():
     if world > 1 and W > 0:
         # the collective of the timed region, once, untimed: RCCL sets up its channels and
         # buffers on first use
-        combine(d_sum.clone(), base, "samples", dst=0)
+        combine(d_sum.clone(), base, "tiles" if tiles else "samples", dst=0)
     ctx.reset_counters()
     sync()
     t0 = time.perf_counter()
     for s in range(W, W + K):
         ctx.render_accumulate(step_params(s, abi.FLAG_PROFILE), d_sum.data_ptr(), stream)
-    full = combine(d_sum, base, "samples", dst=0)
+    full = combine(d_sum, base, "tiles" if tiles else "samples", dst=0)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -221,7 +225,7 @@ def main():
         elapsed = float(t.item())
     ktimes = ctx.kernel_times()
 
-    samples_total = world * K * S * w * h
+    samples_total = (1 if tiles else world) * K * S * w * h
     out = None
     if rank == 0:
         # one instrumented (untimed) step for the work counters; the work is deterministic
@@ -231,7 +235,7 @@ def main():
         torch.cuda.synchronize()
         cnt = ctx.counters()
         del scratch
-        step_samples = S * w * h
+        step_samples = max(1, cnt["samples"])  # rank 0's share of one step (the whole frame unless tiles are sharded)
         cnt["shaded_records"] = cnt["shadow_rays"] // max(1, scene_rays_per_hit(scene, base.area_samples))
         dominant = max(("intersect", "shadow"), key=lambda k: ktimes[k]["ms"])
         kt = ktimes[dominant]
@@ -261,7 +265,7 @@ def main():
             "warmup": W,
             "ms_per_step": elapsed / K * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if tiles else "weak",
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
@@ -276,7 +280,7 @@ def main():
                 "primitives": stats["prims"],
                 "bvh_nodes": stats["nodes"],
                 "scene_bytes": stats["device_bytes"],
-                "sharding": "samples" if world > 1 else "none",
+                "sharding": args.sharding if world > 1 else "none",
                 "cull_negligible": bool(args.cull_negligible),
             },
             "roofline": roofline,
