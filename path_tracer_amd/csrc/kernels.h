@@ -33,6 +33,7 @@ struct DeviceCounters {
   unsigned long long shaded_hits, nan_samples;
   unsigned long long closest_nodes, closest_prims;  // intersect kernel
   unsigned long long shadow_nodes, shadow_prims;    // shadow kernel
+  unsigned int dyn_next[8];                         // per-XCD work counters of the running persistent kernel's dynamic tail (not a statistic)
 };
 
 struct BatchCounts {

@@ -169,9 +169,10 @@ __global__ void __launch_bounds__(kBlock) k_generate(SceneDev S, RenderConst rc,
 // Persistent waves with ray replacement.  Rays differ wildly in how many nodes they
 // visit, and a wave lasts as long as its slowest lane; so a lane whose ray is finished
 // does not wait for the others: once kRefillIdle lanes of a wave are idle they are given
-// new rays.  Every wave owns a fixed, interleaved sequence of 64-ray chunks (chunk
-// numbers wave, wave + W, wave + 2W, ...), so there is no work counter to contend for and
-// rays that are neighbours in the queue still enter a wave together.
+// new rays.  For most of a launch every wave owns a fixed, interleaved sequence of 64-ray
+// chunks (chunk numbers wave, wave + W, wave + 2W, ...), so there is no work counter to contend
+// for and rays that are neighbours in the queue still enter a wave together; the last quarter
+// of the rounds comes from per-XCD counters so that the waves finish together (WorkFeed).
 #ifndef MIPT_REFILL_IDLE
 #define MIPT_REFILL_IDLE 32
 #endif
@@ -193,9 +194,87 @@ __device__ __forceinline__ uint32_t xcd_major_block() {
   return (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
 }
 
-__device__ __forceinline__ uint64_t wave_seq_item(uint32_t i, uint32_t wave, uint32_t n_waves) {
-  return ((uint64_t)(i >> 6) * n_waves + wave) * 64ull + (i & 63u);
+// Work feed of a persistent wave: 64-item chunks.  The first `static_rounds` chunks of a wave are
+// its own (chunk numbers wave, wave + W, ...: no shared counter, neighbouring items enter a wave
+// together); the rest of the launch is handed out chunk by chunk from shared counters, so that
+// the waves finish together instead of each ending with its own last chunk (static alone:
+// k_shadow_any 690 ms per step of the benchmark, with a quarter of the rounds dynamic 620 ms).
+#ifndef MIPT_DYNAMIC_TAIL_EIGHTHS
+#define MIPT_DYNAMIC_TAIL_EIGHTHS 2  // share of the rounds handed out dynamically, in eighths (0: none)
+#endif
+struct WorkFeed {
+  uint64_t base;   // first item of the current chunk
+  uint32_t used;   // items of it already handed out
+  uint32_t round;  // chunks this wave has started
+  uint32_t static_rounds, wave, n_waves;
+  uint32_t tail_first, tail_end;  // chunk numbers of the dynamic part this wave's XCD draws from
+  uint32_t part;                  // which of the (up to eight) runs of the dynamic part that is
+};
+// The dynamic part is split into eight runs of chunks, one per XCD with a counter of its own:
+// workgroups go to the XCDs round-robin, so the waves that share an L2 keep drawing neighbouring
+// chunks, as they do in the static part (xcd_major_block).  (One counter for the whole chip:
+// half the gain.  Moving on to another XCD's run when the own one is used up: measured slower.)
+__device__ __forceinline__ uint64_t feed_chunk(const WorkFeed &f, unsigned int *counters) {
+  if (f.round < f.static_rounds) return ((uint64_t)f.round * f.n_waves + f.wave) * 64ull;
+  uint32_t v = 0;
+  if (lane_id() == 0) v = atomicAdd(counters + f.part, 1u);
+  v = (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+  const uint64_t c = (uint64_t)f.tail_first + v;
+  return c < f.tail_end ? c * 64ull : ~0ull;
 }
+__device__ __forceinline__ void feed_init(WorkFeed &f, uint64_t n_items, uint32_t wave, uint32_t n_waves, unsigned int *counters) {
+  const uint64_t chunks = (n_items + 63ull) / 64ull;
+  const uint64_t rounds = chunks / n_waves;  // whole rounds of static chunks
+  f.static_rounds = MIPT_DYNAMIC_TAIL_EIGHTHS > 0 ? (uint32_t)(rounds - rounds * MIPT_DYNAMIC_TAIL_EIGHTHS / 8) : 0xffffffffu;
+  f.wave = wave;
+  f.n_waves = n_waves;
+  if (MIPT_DYNAMIC_TAIL_EIGHTHS > 0) {
+    const uint64_t t0 = (uint64_t)f.static_rounds * n_waves;
+    const uint32_t parts = min(8u, gridDim.x);  // a launch of fewer than eight blocks does not reach every XCD
+    const uint64_t len = (chunks - t0 + parts - 1u) / parts;
+    f.part = blockIdx.x % parts;
+    f.tail_first = (uint32_t)min(t0 + f.part * len, chunks);
+    f.tail_end = (uint32_t)min(t0 + (f.part + 1ull) * len, chunks);
+  } else {
+    f.tail_first = f.tail_end = 0;
+    f.part = 0;
+  }
+  f.round = 0;
+  f.used = 0;
+  f.base = feed_chunk(f, counters);
+}
+// Takes up to `want` (<= 64) items: the `got` items handed out are first .. first + n1 - 1 and,
+// when the current chunk ran out, first2 .. of the next one; got = 0 when the launch's items are
+// all handed out.  rank r of the takers gets feed_item(r, ...).
+struct FeedTake { uint64_t first, first2; uint32_t n1, got; };
+__device__ __forceinline__ FeedTake feed_take(WorkFeed &f, uint32_t want, uint64_t n_items, unsigned int *counter) {
+  FeedTake t{0, 0, 0, 0};
+  if (f.used == 64u) {
+    f.round++;
+    f.used = 0;
+    f.base = feed_chunk(f, counter);
+  }
+  if (f.base >= n_items) return t;
+  t.first = f.base + f.used;
+  t.n1 = min(want, 64u - f.used);
+  f.used += t.n1;
+  t.got = t.n1;
+  if (t.n1 < want) {  // the rest from the next chunk
+    f.round++;
+    f.base = feed_chunk(f, counter);
+    f.used = 0;
+    if (f.base < n_items) {
+      t.first2 = f.base;
+      f.used = want - t.n1;
+      t.got = want;
+    } else {
+      f.used = 64u;  // stays past the end: the next call finds nothing either
+    }
+  }
+  return t;
+}
+__device__ __forceinline__ uint64_t feed_item(const FeedTake &t, uint32_t r) { return r < t.n1 ? t.first + r : t.first2 + (r - t.n1); }
+
 __device__ __forceinline__ uint32_t rank_below(unsigned long long mask, uint32_t lane) {
   return (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
 }
@@ -217,13 +296,17 @@ __global__ void __launch_bounds__(kBlock, MIPT_TRAV_WAVES) k_intersect(SceneDev 
   T.sp = 0;
   bool idle = true;
   uint32_t ray = 0;
-  uint32_t next = 0;                                      // position in this wave's sequence (wave-uniform)
-  bool exhausted = wave_seq_item(0, wave, n_waves) >= n;  // wave-uniform
+  WorkFeed feed;
+  feed_init(feed, n, wave, n_waves, dc->dyn_next);
+  bool exhausted = false;  // wave-uniform
   while (true) {
     unsigned long long idle_mask = __ballot(idle);
     if (idle_mask != 0ull && !exhausted) {
-      if (idle) {
-        uint64_t item = wave_seq_item(next + rank_below(idle_mask, lane), wave, n_waves);
+      const FeedTake take = feed_take(feed, (uint32_t)__popcll(idle_mask), n, dc->dyn_next);
+      exhausted = take.got == 0u;
+      const uint32_t rnk = rank_below(idle_mask, lane);
+      if (idle && rnk < take.got) {
+        uint64_t item = feed_item(take, rnk);
         if (item < n) {
           ray = (uint32_t)item * dup;
           d3 o{q.ox[ray], q.oy[ray], q.oz[ray]};
@@ -232,8 +315,6 @@ __global__ void __launch_bounds__(kBlock, MIPT_TRAV_WAVES) k_intersect(SceneDev 
           idle = false;
         }
       }
-      next += (uint32_t)__popcll(idle_mask);
-      exhausted = wave_seq_item(next, wave, n_waves) >= n;
     }
     if (__ballot(!idle) == 0ull) break;
     const uint32_t want_idle = exhausted ? 64u : kRefillIdleClosest;
@@ -538,13 +619,17 @@ __global__ void __launch_bounds__(kBlock, MIPT_TRAV_WAVES) k_shadow_any(SceneDev
   bool idle = true;
   uint32_t item = 0;
   double scale = 0.0;
-  uint32_t next = 0;
-  bool exhausted = wave_seq_item(0, wave, n_waves) >= n_items;
+  WorkFeed feed;
+  feed_init(feed, n_items, wave, n_waves, dc->dyn_next);
+  bool exhausted = false;
   while (true) {
     unsigned long long idle_mask = __ballot(idle);
     if (idle_mask != 0ull && !exhausted) {
-      if (idle) {
-        uint64_t it = wave_seq_item(next + rank_below(idle_mask, lane), wave, n_waves);
+      const FeedTake take = feed_take(feed, (uint32_t)__popcll(idle_mask), n_items, dc->dyn_next);
+      exhausted = take.got == 0u;
+      const uint32_t rnk = rank_below(idle_mask, lane);
+      if (idle && rnk < take.got) {
+        uint64_t it = feed_item(take, rnk);
         if (it < n_items) {
           item = (uint32_t)it;
           uint32_t hl = item / R;  // hit within this launch
@@ -561,8 +646,6 @@ __global__ void __launch_bounds__(kBlock, MIPT_TRAV_WAVES) k_shadow_any(SceneDev
           idle = false;
         }
       }
-      next += (uint32_t)__popcll(idle_mask);
-      exhausted = wave_seq_item(next, wave, n_waves) >= n_items;
     }
     if (__ballot(!idle) == 0ull) break;
     const uint32_t want_idle = exhausted ? 64u : kRefillIdle;
@@ -819,6 +902,7 @@ void launch_intersect(const SceneDev &S, const RenderConst &rc, RayQueue q, uint
   if (dup < 1u || n % dup != 0u) dup = 1u;
   uint32_t traced = n / dup;
   auto kern = count ? k_intersect<true> : k_intersect<false>;
+  (void)hipMemsetAsync(dc->dyn_next, 0, sizeof(dc->dyn_next), st);
   hipLaunchKernelGGL(kern, dim3(persistent_grid(rc, traced)), dim3(kBlock), stack_bytes(S), st, S, rc, q, traced, dup, hit_t, hit_prim, dc);
 }
 
@@ -858,6 +942,7 @@ void launch_shadow_trace(const SceneDev &S, const RenderConst &rc, ShadeList sl,
     hipLaunchKernelGGL(kern, dim3(persistent_grid(rc, items)), dim3(kBlock), stack_bytes(S), st, S, rc, sl, first_hit * R, items, vis, dc);
   } else {
     auto kern = count ? k_shadow_any<true> : k_shadow_any<false>;
+    (void)hipMemsetAsync(dc->dyn_next, 0, sizeof(dc->dyn_next), st);
     hipLaunchKernelGGL(kern, dim3(persistent_grid(rc, items)), dim3(kBlock), stack_bytes(S), st, S, rc, sl, (uint32_t)first_hit, items, vis, dc);
   }
 }
