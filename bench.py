@@ -251,11 +251,16 @@ def main():
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
             "traffic": load_traffic(args.workload, dominant),
+            "traffic_frac": None,  # HBM-side bytes per launch / launch time / peak, filled below
+            "note": "achieved = algorithmic bytes (cache-served for this working set, so frac can pass 1); traffic = HBM-side bytes per launch "
+                    "from the committed rocprofv3 counter passes",
             "utilisation": load_utilisation(args.workload, dominant),
             "avg_launch_ms": avg_launch_ms,
             "launches_per_step": launches_step,
             "algorithmic_bytes_per_sample": (algorithmic_bytes(cnt, "intersect") + algorithmic_bytes(cnt, "shadow") + 64 * cnt["shaded_hits"]) / step_samples,
         }
+        if roofline["traffic"] and avg_launch_ms > 0:
+            roofline["traffic_frac"] = roofline["traffic"] / (avg_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
         out = {
             "metric": "path samples/s",
             "value": samples_total / elapsed / 1e6,
