@@ -477,6 +477,8 @@ int mipt_upload_scene(mipt_ctx *c, const mipt_scene_desc *desc) {
     D.stack_ovf = reinterpret_cast<uint32_t *>(p);
   }
   D.translucent = H.translucent ? 1 : 0;
+  D.local_meshes = H.local_meshes ? 1 : 0;
+  D.t_cap = 1000.0;  // every entry point that traces sets it to its own t_max
   D.radius = H.radius;
   std::memcpy(D.ambient, H.ambient, sizeof(D.ambient));
   D.camera = H.camera;
@@ -516,6 +518,7 @@ int mipt_render_accumulate(mipt_ctx *c, const mipt_params *p, double *d_sum, voi
   HIP_TRY(c, hipSetDevice(c->device));
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if ((r = sync_lights(c, p->area_samples)) != MIPT_OK) return r;
+  c->dev.t_cap = p->t_max;
   bool count = (p->flags & MIPT_FLAG_COUNTERS) != 0;
   bool prof = (p->flags & MIPT_FLAG_PROFILE) != 0;
   // a call that fails half way leaves no half-recorded event pairs behind
@@ -750,6 +753,7 @@ int mipt_intersect(mipt_ctx *c, int64_t n, const double *org, const double *dir,
   if (e == hipSuccess) e = hipMemcpy(d_org, org, v3, hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemcpy(d_dir, dir, v3, hipMemcpyHostToDevice);
   if (e == hipSuccess) {
+    c->dev.t_cap = t_max;
     launch_intersect_rays(c->dev, n, d_org, d_dir, t_max, d_t, d_p, d_n, nullptr);
     e = hipDeviceSynchronize();
   }
@@ -777,6 +781,7 @@ int mipt_hit_material(mipt_ctx *c, int64_t n, const double *org, const double *d
   if (e == hipSuccess) e = hipMemcpy(d_org, org, v3, hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemcpy(d_dir, dir, v3, hipMemcpyHostToDevice);
   if (e == hipSuccess) {
+    c->dev.t_cap = t_max;
     launch_hit_material(c->dev, n, d_org, d_dir, t_max, d_uv, d_kd, d_ka, nullptr);
     e = hipDeviceSynchronize();
   }
@@ -798,6 +803,7 @@ int mipt_shadow_attenuation(mipt_ctx *c, const mipt_params *p, int light, int64_
   if (n == 0) return MIPT_OK;
   HIP_TRY(c, hipSetDevice(c->device));
   if ((r = sync_lights(c, p->area_samples)) != MIPT_OK) return r;
+  c->dev.t_cap = p->t_max;
   RenderConst rc = make_const(c, p, 0);
   double *d_f = nullptr, *d_o = nullptr;
   uint64_t *d_k = nullptr;

@@ -42,6 +42,8 @@ struct SceneDev {
   uint32_t *stack_ovf;     // overflow of the traversal stacks: entry k of thread g at [k * ovf_stride + g]
   uint32_t ovf_stride;     // threads the overflow area is laid out for
   int translucent;
+  int local_meshes;  // some mesh object has ObjRec::local_units set: triangle tests look their object up
+  double t_cap;      // the render's t_max: the cap Trimesh::intersectLocal starts every mesh walk with, in LOCAL units (trimesh.cpp:85-86)
   double radius;
   double ambient[3];
   CameraRec camera;
@@ -136,16 +138,32 @@ __device__ __forceinline__ bool analytic_hit(const ObjRec *o, uint32_t kind, d3 
 // w1/w2 are the barycentric weights of the second and third vertex.
 // `tfar`: hits beyond it do not matter to the caller (the walk's current best); they are
 // rejected before the barycentric half of the record is fetched.
-__device__ __forceinline__ bool tri_hit(const Tri *tr, d3 org, d3 dir, double &t, double &w1, double &w2, double tfar = 1.0e300) {
+// `lo`: null, or the object of a mesh whose local units matter (ObjRec::local_units).  The
+// reference runs this test on the local-space ray (p', d' = inv3 d / len, len = |inv3 d|,
+// scene.cpp:18-22): its |n'.d'| equals |n.d| / (|fwdt n| * len) and its t' equals t * len, so
+// the parallel-ray threshold (trimesh.cpp:107-109) becomes |n.d| < 1e-8 * |fwdt n| * len and
+// the cap the mesh walk starts with (trimesh.cpp:85-86) becomes t * len < t_cap.
+// `recheck`: the caller already accepted this hit and only wants its barycentrics back:
+// no threshold applies.
+__device__ __forceinline__ bool tri_hit(const Tri *tr, d3 org, d3 dir, double &t, double &w1, double &w2, double tfar = 1.0e300,
+                                        const ObjRec *lo = nullptr, double t_cap = 0.0, bool recheck = true) {
   const double2 *w = reinterpret_cast<const double2 *>(tr);
   const double2 w0 = w[0], w1_ = w[1], w2_ = w[2];  // one round trip for the plane
   d3 n{w0.x, w0.y, w1_.x};
   double denom = dot(n, dir);
-  if (fabs(denom) < MIPT_RAY_EPSILON) return false;
+  double eps = recheck ? 0.0 : MIPT_RAY_EPSILON;
+  double len = 1.0;
+  if (lo) {
+    len = length(d3{lo->inv[0] * dir.x + lo->inv[1] * dir.y + lo->inv[2] * dir.z, lo->inv[4] * dir.x + lo->inv[5] * dir.y + lo->inv[6] * dir.z,
+                    lo->inv[8] * dir.x + lo->inv[9] * dir.y + lo->inv[10] * dir.z});
+    eps = MIPT_RAY_EPSILON * (length(mul3(lo->fwdt, n)) * len);
+  }
+  if (fabs(denom) < eps) return false;
   d3 a{w1_.y, w2_.x, w2_.y};
   double num = dot(a - org, n);
   double tt = num / denom;
   if (!(tt >= 0) || tt > tfar) return false;
+  if (lo && !(tt * len < t_cap)) return false;
   const double2 w3 = w[3], w4 = w[4], w5 = w[5];  // a second one for the edges
   d3 pa = (org + tt * dir) - a;
   double b1 = dot(pa, d3{w3.x, w3.y, w4.x});
@@ -302,13 +320,20 @@ __device__ __forceinline__ void node_test(const Trav &T, const SceneDev &S, int 
 
 // Tests primitive `s` (storage index) against the ray.  Closest hit (ANY = false): keeps the
 // smallest (t, ref_order).  Any hit: every t < T.best.t counts.  Returns whether T.best changed.
-template <bool ANY>
+// LOCAL: the scene has a mesh with ObjRec::local_units set (SceneDev::local_meshes), so a triangle
+// test looks its object up; scenes without one run kernels compiled without that path.
+template <bool ANY, bool LOCAL>
 __device__ __forceinline__ bool prim_test(Trav &T, const SceneDev &S, uint32_t s) {
   double t;
   bool hit;
   if (s >= (uint32_t)S.n_analytic) {
     double w1, w2;
-    hit = tri_hit(S.tris + s, T.org, T.dir, t, w1, w2, T.best.t);
+    if (LOCAL) {
+      const ObjRec *o = S.objects + (S.prim_info[s] & 0x3fffffffu);
+      hit = tri_hit(S.tris + s, T.org, T.dir, t, w1, w2, T.best.t, o->local_units ? o : nullptr, S.t_cap, false);
+    } else {
+      hit = tri_hit(S.tris + s, T.org, T.dir, t, w1, w2, T.best.t, nullptr, 0.0, false);
+    }
   } else {
     uint32_t info = S.prim_info[s];
     d3 Nl;
@@ -331,7 +356,7 @@ __device__ __forceinline__ bool prim_test(Trav &T, const SceneDev &S, uint32_t s
 // Closest hit (ANY = false): children are entered near to far.  Any hit (ANY = true):
 // children are entered in slot order (the builder puts large boxes first) and the first
 // primitive with t < tmax ends the walk.
-template <bool ANY, bool COUNT>
+template <bool ANY, bool COUNT, bool LOCAL>
 __device__ __forceinline__ void trav_round(Trav &T, const SceneDev &S, const Stack &stk, TravCounters &tc) {
   int cur = T.cur, sp = T.sp;
   while (cur >= 0) {
@@ -388,7 +413,7 @@ __device__ __forceinline__ void trav_round(Trav &T, const SceneDev &S, const Sta
 #else
       if (COUNT) tc.prims++;
 #endif
-      if (prim_test<ANY>(T, S, first + k) && ANY) { found = true; break; }
+      if (prim_test<ANY, LOCAL>(T, S, first + k) && ANY) { found = true; break; }
     }
     if (found || sp == 0) cur = MIPT_TRAV_DONE;
     else cur = (int)stack_pop(S, stk, sp);
@@ -398,11 +423,11 @@ __device__ __forceinline__ void trav_round(Trav &T, const SceneDev &S, const Sta
 }
 
 // The whole walk of one ray.
-template <bool ANY, bool COUNT>
+template <bool ANY, bool COUNT, bool LOCAL>
 __device__ __forceinline__ Hit traverse(const SceneDev &S, d3 org, d3 dir, double tmax, const Stack &stk, TravCounters &tc) {
   Trav T;
   trav_init(T, S, org, dir, tmax);
-  while (T.cur != MIPT_TRAV_DONE) trav_round<ANY, COUNT>(T, S, stk, tc);
+  while (T.cur != MIPT_TRAV_DONE) trav_round<ANY, COUNT, LOCAL>(T, S, stk, tc);
   return T.best;
 }
 

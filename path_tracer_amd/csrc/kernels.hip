@@ -282,7 +282,7 @@ __device__ __forceinline__ uint32_t rank_below(unsigned long long mask, uint32_t
 // `dup` > 1: the queue holds runs of `dup` identical rays (the camera rays of one pixel's
 // samples, RayTracer.cpp:72-75 calls trace(x, y) N times with the same x, y); only the first
 // ray of every run is traced, k_shade reads its result for the whole run.  n = rays to trace.
-template <bool COUNT>
+template <bool COUNT, bool LOCAL>
 __global__ void __launch_bounds__(kBlock, MIPT_TRAV_WAVES) k_intersect(SceneDev S, RenderConst rc, RayQueue q, uint32_t n, uint32_t dup,
                                                                         double *__restrict__ hit_t, int *__restrict__ hit_prim, DeviceCounters *dc) {
   extern __shared__ uint32_t lds_stack[];
@@ -319,7 +319,7 @@ __global__ void __launch_bounds__(kBlock, MIPT_TRAV_WAVES) k_intersect(SceneDev 
     if (__ballot(!idle) == 0ull) break;
     const uint32_t want_idle = exhausted ? 64u : kRefillIdleClosest;
     do {
-      trav_round<false, COUNT>(T, S, stack, tc);
+      trav_round<false, COUNT, LOCAL>(T, S, stack, tc);
       if (!idle && T.cur == MIPT_TRAV_DONE) {
         hit_t[ray] = T.best.t;
         hit_prim[ray] = T.best.prim;
@@ -499,18 +499,18 @@ __global__ void __launch_bounds__(kShadeBlock) k_shade(SceneDev S, RenderConst r
 
 // ------------------------------------------------------------------ shadow ----
 // The occluder walk of light.cpp:21-33 / 70-83 / 125-138 for translucent scenes.
-template <bool COUNT>
+template <bool COUNT, bool LOCAL>
 __device__ d3 shadow_walk(const SceneDev &S, d3 light, d3 p, d3 d, bool has_target, d3 target, double lightT, double tmax,
                           const Stack &stack, TravCounters &tc) {
   int mat = -1;
-  Hit h = traverse<false, COUNT>(S, p, d, tmax, stack, tc);
+  Hit h = traverse<false, COUNT, LOCAL>(S, p, d, tmax, stack, tc);
   double pt = h.t;
   if (h.prim >= 0) mat = S.objects[S.prim_info[h.prim] & 0x3fffffffu].material;
   int guard = 0;
   while (pt < lightT && guard++ < 4096) {
     d3 entry = p + pt * d;
     p = p + (pt + MIPT_RAY_EPSILON) * d;
-    h = traverse<false, COUNT>(S, p, d, tmax, stack, tc);
+    h = traverse<false, COUNT, LOCAL>(S, p, d, tmax, stack, tc);
     pt = h.t;
     if (h.prim >= 0) mat = S.objects[S.prim_info[h.prim] & 0x3fffffffu].material;
     d3 exitp = p + pt * d;
@@ -518,7 +518,7 @@ __device__ d3 shadow_walk(const SceneDev &S, d3 light, d3 p, d3 d, bool has_targ
     d3 kt = mat >= 0 ? ld3(S.materials[mat].kt) : d3{0, 0, 0};
     light = light * d3{pow(kt.x, dist), pow(kt.y, dist), pow(kt.z, dist)};
     p = p + (pt + MIPT_RAY_EPSILON) * d;
-    h = traverse<false, COUNT>(S, p, d, tmax, stack, tc);
+    h = traverse<false, COUNT, LOCAL>(S, p, d, tmax, stack, tc);
     pt = h.t;
     if (h.prim >= 0) mat = S.objects[S.prim_info[h.prim] & 0x3fffffffu].material;
     if (has_target) lightT = sqrt(dot(target - p, target - p));
@@ -573,18 +573,18 @@ __device__ __forceinline__ ShadowSetup shadow_setup(const RenderConst &rc, const
 
 // One whole shadow ray (test hook and the translucent kernel): Light::shadowAttenuation's
 // per-ray value, area 1/S excluded.
-template <bool COUNT, bool WALK>
+template <bool COUNT, bool WALK, bool LOCAL>
 __device__ d3 shadow_ray(const SceneDev &S, const RenderConst &rc, const LightRec &L, int li, int s, d3 fire, uint64_t key,
                          const Stack &stack, TravCounters &tc) {
   ShadowSetup su = shadow_setup(rc, L, li, s, fire, key);
   d3 color = ld3(L.color);
   d3 light;
   if (WALK) {
-    light = shadow_walk<COUNT>(S, color, fire, su.dir, su.has_target, su.target, su.lightT, rc.t_max, stack, tc);
+    light = shadow_walk<COUNT, LOCAL>(S, color, fire, su.dir, su.has_target, su.target, su.lightT, rc.t_max, stack, tc);
   } else {
     // every kt is 0: the walk multiplies by pow(0, dist > 0) = 0 on the first occluder,
     // so "any hit closer than the light" decides it
-    Hit h = traverse<true, COUNT>(S, fire, su.dir, fmin(su.lightT, rc.t_max), stack, tc);
+    Hit h = traverse<true, COUNT, LOCAL>(S, fire, su.dir, fmin(su.lightT, rc.t_max), stack, tc);
     light = h.prim >= 0 ? d3{0, 0, 0} : color;
   }
   return light * su.scale;
@@ -603,7 +603,7 @@ __device__ __forceinline__ int light_of_ray(const SceneDev &S, uint32_t r) {
 // k_intersect).  Work item w = hit * rays_per_hit + ray, hits counted from `first_hit`: the
 // rays of one hit are adjacent and enter a wave together, so they share origin and target
 // region.  Result per ray: vis[w] = 0 if occluded, else the sample's attenuation scale.
-template <bool COUNT>
+template <bool COUNT, bool LOCAL>
 __global__ void __launch_bounds__(kBlock, MIPT_TRAV_WAVES) k_shadow_any(SceneDev S, RenderConst rc, ShadeList sl, uint32_t first_hit, uint32_t n_items,
                                                                          double *__restrict__ vis, DeviceCounters *dc) {
   extern __shared__ uint32_t lds_stack[];
@@ -650,7 +650,7 @@ __global__ void __launch_bounds__(kBlock, MIPT_TRAV_WAVES) k_shadow_any(SceneDev
     if (__ballot(!idle) == 0ull) break;
     const uint32_t want_idle = exhausted ? 64u : kRefillIdle;
     do {
-      trav_round<true, COUNT>(T, S, stack, tc);
+      trav_round<true, COUNT, LOCAL>(T, S, stack, tc);
       if (!idle && T.cur == MIPT_TRAV_DONE) {
         vis[item] = T.best.prim >= 0 ? 0.0 : scale;
         idle = true;
@@ -665,7 +665,7 @@ __global__ void __launch_bounds__(kBlock, MIPT_TRAV_WAVES) k_shadow_any(SceneDev
 
 // Translucent scenes: the full occluder walk, one lane per ray; vis3 holds the walk's colour
 // times the sample scale.
-template <bool COUNT>
+template <bool COUNT, bool LOCAL>
 __global__ void __launch_bounds__(kBlock, 2) k_shadow_walk(SceneDev S, RenderConst rc, ShadeList sl, uint64_t first_item, uint32_t n_items,
                                                             double *__restrict__ vis3, DeviceCounters *dc) {
   extern __shared__ uint32_t lds_stack[];
@@ -681,7 +681,7 @@ __global__ void __launch_bounds__(kBlock, 2) k_shadow_walk(SceneDev S, RenderCon
     d3 P{sl.px[h], sl.py[h], sl.pz[h]};
     d3 N{sl.nx[h], sl.ny[h], sl.nz[h]};
     d3 fire = P + (N * MIPT_RAY_EPSILON) * 3.0;
-    d3 light = shadow_ray<COUNT, true>(S, rc, L, li, (int)r - L.first_ray, fire, sl.key[h], stack, tc);
+    d3 light = shadow_ray<COUNT, true, LOCAL>(S, rc, L, li, (int)r - L.first_ray, fire, sl.key[h], stack, tc);
     vis3[3ull * it + 0] = light.x;
     vis3[3ull * it + 1] = light.y;
     vis3[3ull * it + 2] = light.z;
@@ -799,6 +799,7 @@ __global__ void __launch_bounds__(kBlock) k_finalize(const double *__restrict__ 
 }
 
 // -------------------------------------------------------------- test hooks ----
+template <bool LOCAL>
 __global__ void __launch_bounds__(kBlock) k_intersect_rays(SceneDev S, int64_t n, const double *__restrict__ org, const double *__restrict__ dir,
                                                             double t_max, double *t, int *prim, double *normal) {
   extern __shared__ uint32_t lds_stack[];
@@ -807,7 +808,7 @@ __global__ void __launch_bounds__(kBlock) k_intersect_rays(SceneDev S, int64_t n
   for (int64_t idx = stack.gtid; idx < n; idx += (int64_t)gridDim.x * kBlock) {
     d3 o{org[3 * idx], org[3 * idx + 1], org[3 * idx + 2]};
     d3 d{dir[3 * idx], dir[3 * idx + 1], dir[3 * idx + 2]};
-    Hit h = traverse<false, false>(S, o, d, t_max, stack, tc);
+    Hit h = traverse<false, false, LOCAL>(S, o, d, t_max, stack, tc);
     t[idx] = h.t;
     prim[idx] = h.prim >= 0 ? (int)S.ref_order[h.prim] : -1;
     d3 N{0, 0, 0};
@@ -818,6 +819,7 @@ __global__ void __launch_bounds__(kBlock) k_intersect_rays(SceneDev S, int64_t n
   }
 }
 
+template <bool LOCAL>
 __global__ void __launch_bounds__(kBlock) k_hit_material(SceneDev S, int64_t n, const double *__restrict__ org, const double *__restrict__ dir,
                                                           double t_max, double *uv, double *kd_out, double *ka_out) {
   extern __shared__ uint32_t lds_stack[];
@@ -826,7 +828,7 @@ __global__ void __launch_bounds__(kBlock) k_hit_material(SceneDev S, int64_t n, 
   for (int64_t idx = stack.gtid; idx < n; idx += (int64_t)gridDim.x * kBlock) {
     d3 o{org[3 * idx], org[3 * idx + 1], org[3 * idx + 2]};
     d3 d{dir[3 * idx], dir[3 * idx + 1], dir[3 * idx + 2]};
-    Hit h = traverse<false, false>(S, o, d, t_max, stack, tc);
+    Hit h = traverse<false, false, LOCAL>(S, o, d, t_max, stack, tc);
     double u = 0, v = 0;
     d3 kd{0, 0, 0}, ka{0, 0, 0};
     if (h.prim >= 0) {
@@ -845,7 +847,7 @@ __global__ void __launch_bounds__(kBlock) k_hit_material(SceneDev S, int64_t n, 
   }
 }
 
-template <bool WALK>
+template <bool WALK, bool LOCAL>
 __global__ void __launch_bounds__(kBlock) k_shadow_attenuation(SceneDev S, RenderConst rc, int li, int64_t n, const double *__restrict__ fire,
                                                                 const uint64_t *__restrict__ key, double *out) {
   extern __shared__ uint32_t lds_stack[];
@@ -855,7 +857,7 @@ __global__ void __launch_bounds__(kBlock) k_shadow_attenuation(SceneDev S, Rende
   for (int64_t idx = stack.gtid; idx < n; idx += (int64_t)gridDim.x * kBlock) {
     d3 f{fire[3 * idx], fire[3 * idx + 1], fire[3 * idx + 2]};
     d3 sum{0, 0, 0};
-    for (int s = 0; s < L.samples; s++) sum = sum + shadow_ray<false, WALK>(S, rc, L, li, s, f, key[idx], stack, tc);
+    for (int s = 0; s < L.samples; s++) sum = sum + shadow_ray<false, WALK, LOCAL>(S, rc, L, li, s, f, key[idx], stack, tc);
     if (L.type == MIPT_LIGHT_RECT_AREA) sum = sum / (double)L.samples;
     out[3 * idx] = sum.x;
     out[3 * idx + 1] = sum.y;
@@ -901,7 +903,7 @@ void launch_intersect(const SceneDev &S, const RenderConst &rc, RayQueue q, uint
   if (!n) return;
   if (dup < 1u || n % dup != 0u) dup = 1u;
   uint32_t traced = n / dup;
-  auto kern = count ? k_intersect<true> : k_intersect<false>;
+  auto kern = S.local_meshes ? (count ? k_intersect<true, true> : k_intersect<false, true>) : (count ? k_intersect<true, false> : k_intersect<false, false>);
   (void)hipMemsetAsync(dc->dyn_next, 0, sizeof(dc->dyn_next), st);
   hipLaunchKernelGGL(kern, dim3(persistent_grid(rc, traced)), dim3(kBlock), stack_bytes(S), st, S, rc, q, traced, dup, hit_t, hit_prim, dc);
 }
@@ -938,10 +940,10 @@ void launch_shadow_trace(const SceneDev &S, const RenderConst &rc, ShadeList sl,
   if (!n_hits || !R) return;
   uint32_t items = (uint32_t)(n_hits * R);
   if (S.translucent) {
-    auto kern = count ? k_shadow_walk<true> : k_shadow_walk<false>;
+    auto kern = S.local_meshes ? (count ? k_shadow_walk<true, true> : k_shadow_walk<false, true>) : (count ? k_shadow_walk<true, false> : k_shadow_walk<false, false>);
     hipLaunchKernelGGL(kern, dim3(persistent_grid(rc, items)), dim3(kBlock), stack_bytes(S), st, S, rc, sl, first_hit * R, items, vis, dc);
   } else {
-    auto kern = count ? k_shadow_any<true> : k_shadow_any<false>;
+    auto kern = S.local_meshes ? (count ? k_shadow_any<true, true> : k_shadow_any<false, true>) : (count ? k_shadow_any<true, false> : k_shadow_any<false, false>);
     (void)hipMemsetAsync(dc->dyn_next, 0, sizeof(dc->dyn_next), st);
     hipLaunchKernelGGL(kern, dim3(persistent_grid(rc, items)), dim3(kBlock), stack_bytes(S), st, S, rc, sl, (uint32_t)first_hit, items, vis, dc);
   }
@@ -973,19 +975,19 @@ void launch_finalize(const double *d_sum, int64_t n_pixels, int spp, float *rgb_
 void launch_intersect_rays(const SceneDev &S, int64_t n, const double *org, const double *dir, double t_max, double *t, int *prim,
                            double *normal, hipStream_t st) {
   if (!n) return;
-  hipLaunchKernelGGL(k_intersect_rays, dim3(bounded_grid(S, (uint64_t)n)), dim3(kBlock), stack_bytes(S), st, S, n, org, dir, t_max, t, prim, normal);
+  hipLaunchKernelGGL(S.local_meshes ? k_intersect_rays<true> : k_intersect_rays<false>, dim3(bounded_grid(S, (uint64_t)n)), dim3(kBlock), stack_bytes(S), st, S, n, org, dir, t_max, t, prim, normal);
 }
 
 void launch_hit_material(const SceneDev &S, int64_t n, const double *org, const double *dir, double t_max, double *uv, double *kd, double *ka,
                          hipStream_t st) {
   if (!n) return;
-  hipLaunchKernelGGL(k_hit_material, dim3(bounded_grid(S, (uint64_t)n)), dim3(kBlock), stack_bytes(S), st, S, n, org, dir, t_max, uv, kd, ka);
+  hipLaunchKernelGGL(S.local_meshes ? k_hit_material<true> : k_hit_material<false>, dim3(bounded_grid(S, (uint64_t)n)), dim3(kBlock), stack_bytes(S), st, S, n, org, dir, t_max, uv, kd, ka);
 }
 
 void launch_shadow_attenuation(const SceneDev &S, const RenderConst &rc, int light, int64_t n, const double *fire, const uint64_t *key,
                                double *out, hipStream_t st) {
   if (!n) return;
-  auto kern = S.translucent ? k_shadow_attenuation<true> : k_shadow_attenuation<false>;
+  auto kern = S.local_meshes ? (S.translucent ? k_shadow_attenuation<true, true> : k_shadow_attenuation<false, true>) : (S.translucent ? k_shadow_attenuation<true, false> : k_shadow_attenuation<false, false>);
   hipLaunchKernelGGL(kern, dim3(bounded_grid(S, (uint64_t)n)), dim3(kBlock), stack_bytes(S), st, S, rc, light, n, fire, key, out);
 }
 

@@ -76,16 +76,28 @@ struct TexRec {
 
 // One scene object (file order).  inv = rows 0..2 of the inverse transform,
 // row-major 3x4 (MatrixTransform::globalToLocalCoords, scene.h:80-82); normi =
-// transpose(inverse(mat3(xform))), row-major 3x3 (scene.h:76,92-94).
+// transpose(inverse(mat3(xform))), row-major 3x3 (scene.h:76,92-94); fwdt =
+// transpose(mat3(xform)), row-major 3x3: fwdt * (world normal of a face) is parallel to the
+// face's local normal and |fwdt * n| is what the local unit normal shrinks by on its way to
+// world space.
 struct alignas(8) ObjRec {
   double inv[12];
   double normi[9];
+  double fwdt[9];
   int32_t kind;
   int32_t material;
   int32_t smooth;  // mesh has per-vertex normals
   int32_t has_uv;  // mesh has per-vertex UV coordinates
   int32_t has_colors;  // mesh has per-vertex colours and no UV coordinates (trimesh.cpp:170-189)
-  int32_t pad;
+  // Mesh whose local units differ from world units enough to matter: the reference tests
+  // faces in the mesh's local space, where a world distance t reads t * |inv3 * d|
+  // (scene.cpp:18-22,33), and two of its thresholds are therefore in local units: hits at
+  // local t >= t_max are misses (trimesh.cpp:85-86) and rays with |n.d| < 1e-8 between the
+  // local unit normal and the local unit direction miss the face (trimesh.cpp:107-109).
+  // Set when the inverse transform stretches some direction (largest singular value > 1)
+  // or is anisotropic (the two thresholds then differ between the spaces); triangles of
+  // such an object are tested with both thresholds carried over to world space.
+  int32_t local_units;
 };
 
 // Material record as shadeBRDF reads it (material.cpp:88-109).  Scalars already

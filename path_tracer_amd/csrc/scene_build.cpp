@@ -117,6 +117,39 @@ struct Box6 {
   }
 };
 
+// Largest and smallest singular value of a row-major 3x3 matrix: square roots of the extreme
+// eigenvalues of A^T A, by cyclic Jacobi rotations (a 3x3 symmetric matrix converges to
+// rounding in a few sweeps).
+void singular_range3(const double *a, double *smax, double *smin) {
+  double s[3][3];
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) s[i][j] = a[i] * a[j] + a[3 + i] * a[3 + j] + a[6 + i] * a[6 + j];
+  for (int sweep = 0; sweep < 32; sweep++) {
+    double off = std::fabs(s[0][1]) + std::fabs(s[0][2]) + std::fabs(s[1][2]);
+    if (off <= 1e-300 || off <= 1e-18 * (std::fabs(s[0][0]) + std::fabs(s[1][1]) + std::fabs(s[2][2]))) break;
+    for (int p = 0; p < 2; p++)
+      for (int q = p + 1; q < 3; q++) {
+        if (s[p][q] == 0.0) continue;
+        double theta = (s[q][q] - s[p][p]) / (2.0 * s[p][q]);
+        double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+        double c = 1.0 / std::sqrt(t * t + 1.0), sn = t * c;
+        for (int k = 0; k < 3; k++) {  // columns p, q
+          double kp = s[k][p], kq = s[k][q];
+          s[k][p] = c * kp - sn * kq;
+          s[k][q] = sn * kp + c * kq;
+        }
+        for (int k = 0; k < 3; k++) {  // rows p, q
+          double pk = s[p][k], qk = s[q][k];
+          s[p][k] = c * pk - sn * qk;
+          s[q][k] = sn * pk + c * qk;
+        }
+      }
+  }
+  double hi = std::max(s[0][0], std::max(s[1][1], s[2][2])), lo = std::min(s[0][0], std::min(s[1][1], s[2][2]));
+  *smax = std::sqrt(std::max(hi, 0.0));
+  *smin = std::sqrt(std::max(lo, 0.0));
+}
+
 inline float round_down(double v) {
   float f = (float)v;
   if ((double)f > v) f = std::nextafterf(f, -std::numeric_limits<float>::infinity());
@@ -589,6 +622,21 @@ int build_host_scene(const mipt_scene_desc *d, HostScene *out, std::string *err,
     for (int r = 0; r < 3; r++)
       for (int c = 0; c < 4; c++) o.inv[4 * r + c] = M(inv, r, c);
     if (!normal_matrix(src.xform, o.normi)) return fail(MIPT_ERR_INVALID, "singular object transform");
+    for (int r = 0; r < 3; r++)
+      for (int c = 0; c < 3; c++) o.fwdt[3 * r + c] = M(src.xform, c, r);
+    if (src.type == MIPT_OBJ_TRIMESH) {
+      // the reference's two face thresholds live in the mesh's local units (trimesh.cpp:85-86,
+      // 107-109); they coincide with their world-space forms unless the inverse transform
+      // stretches a direction (local t = world t * |inv3 d| can pass t_max first) or is
+      // anisotropic (the angle between ray and face differs between the spaces)
+      const double inv3[9] = {o.inv[0], o.inv[1], o.inv[2], o.inv[4], o.inv[5], o.inv[6], o.inv[8], o.inv[9], o.inv[10]};
+      double smax, smin;
+      singular_range3(inv3, &smax, &smin);
+      if (smax > 1.0 + 1e-9 || smax > smin * (1.0 + 1e-9)) {
+        o.local_units = 1;
+        S.local_meshes = true;
+      }
+    }
     o.kind = src.type;
     o.material = src.material;
     D3 mn{0, 0, 0}, mx{0, 0, 0};

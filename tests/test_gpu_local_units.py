@@ -1,0 +1,155 @@
+"""Meshes whose local units differ from world units.
+
+The reference intersects a mesh in its LOCAL space (Geometry::intersect, scene.cpp:13-40):
+the ray is transformed, its direction re-normalised, and t is divided by the local ray
+length on the way back.  Two thresholds of the face test are therefore in local units:
+
+  * Trimesh::intersectLocal starts the face walk at t = 1000 (trimesh.cpp:85-86): a face at
+    local distance >= 1000 is a miss, i.e. world distance >= 1000 / |inv3 d|.  A mesh under
+    scale(0.01) disappears beyond world distance 10.
+  * TrimeshFace::intersectLocal rejects |n.d| < 1e-8 between the local unit normal and the
+    local unit direction (trimesh.cpp:107-109): under a non-uniform scale that is a different
+    set of rays than the same test in world space.
+
+The library stores world-space triangles and must reproduce both.  Per ray against the oracle
+(which restates the local-space walk), a closed-form check that does not involve the oracle,
+and frames whose shadow rays depend on the cap.
+"""
+import math
+
+import numpy as np
+import pytest
+
+from path_tracer_amd import abi
+from tests import util as U
+from tests.test_gpu_parity import assert_images_match, assert_rays_match, upload
+
+pytestmark = pytest.mark.gpu
+
+
+def _inv_len(xf, d):
+    """|inv3 d|: the factor between world t and local t."""
+    return np.linalg.norm(d @ np.linalg.inv(np.asarray(xf)[:3, :3]).T, axis=1)
+
+
+def _scaled_scene(cfg, n=24, smooth=False, lights=(), extra=()):
+    xf, size, height = cfg
+    objs = [(abi.OBJ_TRIMESH, xf, U.material(kd=(0.7, 0.6, 0.5)), 0)] + list(extra)
+    return U.scene(objs, meshes=[U.grid_mesh(n, size, height, seed=3, smooth=smooth)], lights=list(lights),
+                   cam=U.camera(eye=(0.0137, -0.0071, 0), viewdir=(0.003, 0.002, -1)))  # off the grid's symmetry planes: no ray runs along a shared edge
+
+
+XFORMS = {
+    # world size 20 x 20 at distance 9: local t runs from ~860 to ~1150 over the camera's field of view
+    "scale_0.01": (U.translate(0, 0, -9) @ U.scale(0.01), 1000.0, 40.0),
+    # local units a hundred times smaller than world units: the cap can never bind
+    "scale_100": (U.translate(0, 0, -9) @ U.scale(100.0), 0.1, 0.004),
+    # strongly non-uniform and rotated: |inv3 d| runs from ~1 to ~100 with the direction
+    "nonuniform": (U.translate(0.5, -0.3, -9) @ U.rot_y(0.5) @ U.rot_x(-0.3) @ U.scale(0.01, 0.2, 1.0), 1000.0, 0.4),
+    # mirrored (negative determinant) and stretched the other way round
+    "mirrored": (U.translate(0, 0, -7) @ U.rot_x(0.4) @ U.scale(-0.012, 0.009, 0.0075), 1000.0, 60.0),
+}
+
+
+@pytest.mark.parametrize("name", sorted(XFORMS))
+def test_scaled_mesh_per_ray(name, gpu, oracle_lib):
+    xf = XFORMS[name][0]
+    sc = _scaled_scene(XFORMS[name], smooth=(name == "nonuniform"))
+    orc = oracle_lib.Oracle(sc)
+    upload(gpu, sc)
+    org, d = U.camera_rays(sc, 30000, seed=11)
+    to, po, no = orc.intersect(org, d)
+    tg, pg, ng = gpu.intersect(org, d)
+    assert_rays_match((tg, pg, ng), (to, po, no), min_same=0.9998)
+    hit = po >= 0
+    assert 0.02 < hit.mean()
+    # the oracle-independent part: no accepted hit lies at local t >= 1000
+    tl = tg * _inv_len(xf, d)
+    assert np.all(tl[pg >= 0] < 1000.0 * (1 + 1e-12))
+    if name != "scale_100":
+        assert 0.02 < (~hit).mean(), "the cap must cut some rays off in this set-up"
+        # ... and the rays it cut off do cross the mesh: with the cap lifted they hit it beyond it
+        t2, p2, _ = gpu.intersect(org, d, t_max=1.0e6)
+        far = (pg < 0) & (p2 >= 0)
+        assert far.sum() > 0.5 * (pg < 0).sum()
+        assert np.all((t2 * _inv_len(xf, d))[far] >= 1000.0 * (1 - 1e-12))
+    # secondary rays from the hit points (bounce- and mirror-style origins)
+    P = org[hit] + to[hit, None] * d[hit]
+    d2 = U.random_dirs(len(P), seed=12)
+    assert_rays_match(gpu.intersect(P + d2 * 1e-8, d2), orc.intersect(P + d2 * 1e-8, d2), min_same=0.9998)
+
+
+def test_cap_is_in_local_units_closed_form(gpu):
+    """One flat quad, no oracle: under scale(s) the face at world distance D is hit iff D / s < 1000."""
+    for s, dist, expect in ((0.01, 9.0, True), (0.01, 10.5, False), (0.5, 400.0, True), (0.5, 600.0, False), (4.0, 990.0, True)):
+        sc = U.scene([(abi.OBJ_TRIMESH, U.translate(0, 0, -dist) @ U.scale(s), U.material(), 0)], meshes=[U.quad_mesh()], cam=U.camera(eye=(0, 0, 0)))
+        upload(gpu, sc)
+        t, prim, n = gpu.intersect([[0.1 * s, 0.2 * s, 0.0]], [[0.0, 0.0, -1.0]])
+        if expect:
+            assert prim[0] >= 0 and t[0] == pytest.approx(dist, rel=1e-12) and np.allclose(n[0], [0, 0, 1])
+        else:
+            assert prim[0] == -1 and t[0] == 1000.0
+
+
+@pytest.mark.parametrize("zscale", [50.0, 0.02])
+def test_parallel_ray_threshold_is_in_local_units(zscale, gpu, oracle_lib):
+    """Rays at a grazing angle delta to a face: the reference misses iff delta < 1e-8 in LOCAL
+    space (trimesh.cpp:107-109).  Under scale(1, 1, zscale) the world-space angle is zscale times
+    the local one, so a world-space test answers differently for delta in (1e-8 / zscale, 1e-8)."""
+    xf = U.rot_y(0.3) @ U.scale(1.0, 1.0, zscale)
+    sc = U.scene([(abi.OBJ_TRIMESH, xf, U.material(), 0)], meshes=[U.quad_mesh()], cam=U.camera(eye=(0, 0, 5)))
+    orc = oracle_lib.Oracle(sc)
+    upload(gpu, sc)
+    M = np.asarray(xf)
+    rng = np.random.RandomState(5)
+    n_rays = 400
+    delta = np.where(rng.rand(n_rays) < 0.5, rng.uniform(0.2e-8, 0.8e-8, n_rays), rng.uniform(1.3e-8, 5e-8, n_rays))
+    phi = rng.uniform(0, 2 * math.pi, n_rays)
+    dl = np.stack([np.cos(phi), np.sin(phi), -delta], 1)           # local direction, angle delta to the plane z = 0
+    dl /= np.linalg.norm(dl, axis=1)[:, None]
+    Pl = np.concatenate([rng.uniform(-0.4, 0.4, (n_rays, 2)), np.zeros((n_rays, 1))], 1)
+    ol = Pl - 0.3 * dl                                              # local origin, 0.3 before the crossing
+    ow = ol @ M[:3, :3].T + M[:3, 3]
+    dw = dl @ M[:3, :3].T
+    dw /= np.linalg.norm(dw, axis=1)[:, None]
+    to, po, _ = orc.intersect(ow, dw)
+    tg, pg, _ = gpu.intersect(ow, dw)
+    # closed form first: the local angle decides (rays well away from the threshold on both sides)
+    expect_hit = delta > 1e-8
+    assert np.array_equal(po >= 0, expect_hit), "oracle disagrees with the closed form"
+    assert np.array_equal(pg >= 0, expect_hit)
+    assert np.array_equal(pg, po)
+    # t of a grazing hit is ill-conditioned (numerator and denominator are ~1e-8 with absolute errors ~1e-15): relative 1e-5
+    h = expect_hit
+    assert np.allclose(tg[h], to[h], rtol=1e-5, atol=0)
+
+
+@pytest.mark.parametrize("name", ["scale_0.01", "nonuniform"])
+def test_scaled_mesh_frames(name, gpu, oracle_lib):
+    """Shadow rays depend on the cap too: an occluding face at local distance >= 1000 does not
+    shadow (the light's walk calls the same Scene::intersect, light.cpp:21,70,125)."""
+    floor = (abi.OBJ_SQUARE, U.translate(0, -2.5, -9) @ U.rot_x(-math.pi / 2) @ U.scale(60), U.material(kd=(0.8, 0.8, 0.8)))
+    lights = [U.dir_light((0.2, -1.0, -0.4)), U.point_light((3, 6, 2), atten=(1, 0, 0)), U.area_light((-2, 5, -6), (1, 0, 0), (0, 0, 1), 2, 2)]
+    sc = _scaled_scene(XFORMS[name], lights=lights, extra=[floor])
+    orc = oracle_lib.Oracle(sc)
+    upload(gpu, sc)
+    # per light, at the camera's hit points
+    org, d = U.camera_rays(sc, 6000, seed=21)
+    t, prim, n = orc.intersect(org, d)
+    hit = prim >= 0
+    fire = org[hit] + t[hit, None] * d[hit] + n[hit] * 3e-8
+    keys = np.arange(len(fire), dtype=np.uint64) * np.uint64(104729) + np.uint64(7)
+    p = abi.default_params(8, 8)
+    for li in range(len(lights)):
+        a, b = gpu.shadow_attenuation(p, li, fire, keys), orc.shadow_attenuation(p, li, fire, keys)
+        bad = np.abs(a - b).max(axis=1) > 1e-9
+        assert bad.mean() <= 2e-3, f"light {li}: {bad.sum()} of {len(fire)} shading points differ"
+    p = abi.default_params(96, 96, spp=1, rr_q=0.0, max_depth=4, flags=abi.FLAG_FIXED_AREA_PATTERN)
+    f32, rgb8 = gpu.render(p)
+    ref, ref8 = orc.render(p, threads=8, want_rgb8=True)
+    assert ref.mean() > 0.01
+    assert_images_match(f32, ref, rgb8, ref8, frac=0.997)
+    p = abi.default_params(64, 64, spp=6)
+    f32, rgb8 = gpu.render(p)
+    ref, ref8 = orc.render(p, threads=8, want_rgb8=True)
+    assert_images_match(f32, ref, rgb8, ref8, frac=0.997)

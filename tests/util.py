@@ -98,3 +98,20 @@ def rmsd(a, b):
     a = np.asarray(a, np.float64)
     b = np.asarray(b, np.float64)
     return float(np.linalg.norm((a - b).ravel()) / math.sqrt(a.size))
+
+
+def grid_mesh(n, size, height, seed=0, smooth=False):
+    """An n x n displaced grid of 2 n^2 triangles over [-size, size]^2 in the local z = 0 plane,
+    heights uniform in [-height, height]."""
+    rng = np.random.RandomState(seed)
+    xs = np.linspace(-size, size, n + 1)
+    gx, gy = np.meshgrid(xs, xs, indexing="ij")
+    v = np.stack([gx.ravel(), gy.ravel(), rng.uniform(-height, height, gx.size)], 1)
+    idx = np.arange((n + 1) * (n + 1)).reshape(n + 1, n + 1)
+    a, b, c, d = idx[:-1, :-1].ravel(), idx[1:, :-1].ravel(), idx[1:, 1:].ravel(), idx[:-1, 1:].ravel()
+    f = np.concatenate([np.stack([a, b, c], 1), np.stack([a, c, d], 1)]).astype(np.int32)
+    normals = None
+    if smooth:
+        normals = np.tile(np.array([[0.0, 0.0, 1.0]]), (len(v), 1)) + rng.normal(scale=0.2, size=(len(v), 3))
+        normals /= np.linalg.norm(normals, axis=1)[:, None]
+    return MeshRec(v, f, normals)
