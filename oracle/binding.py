@@ -58,6 +58,9 @@ def load():
     lib.orc_object_order.argtypes = [vp, vp]
     lib.orc_cubemap_color.restype = C.c_int
     lib.orc_cubemap_color.argtypes = [vp, i64, vp, vp]
+    lib.orc_set_mutation.restype = C.c_int
+    lib.orc_set_mutation.argtypes = [C.c_int]
+    lib.orc_mutation_count.restype = C.c_int
     lib.orc_uniform.restype = dbl
     lib.orc_uniform.argtypes = [C.c_uint64, C.c_uint64]
     lib.orc_mix.restype = C.c_uint64
@@ -185,3 +188,16 @@ def mix(key, j):
 
 def sample_key(seed, pixel, sample):
     return load().orc_sample_key(seed, pixel, sample)
+
+
+MUTATIONS = ("none", "no_rr_compensation", "no_mirror_halving", "shadowed_specular", "fixed_sample_point", "coloured_specular",
+             "sphere_normal_faces_ray", "cosine_pdf", "clamp_after_mean", "abs_n_dot_v", "square_normal_fixed", "no_rr_at_depth_0",
+             "roughness_as_alpha", "no_indirect_specular", "diffuse_ignores_metallic", "float_free_hemisphere")
+
+
+def set_mutation(name: str = "none") -> None:
+    """Switches the (process-wide) oracle to one of its mutants; "none" restores the faithful restatement."""
+    lib = load()
+    assert lib.orc_mutation_count() == len(MUTATIONS)
+    if lib.orc_set_mutation(MUTATIONS.index(name)) != 0:
+        raise ValueError(name)

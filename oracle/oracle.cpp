@@ -35,6 +35,31 @@ namespace {
 
 thread_local std::string g_err;
 
+// Mutation switch, 0 in every use but one: tests/test_reference_screenshots.py turns single
+// quirks of the reference OFF (or common mistakes ON) to measure which of them the
+// screenshot pin can tell apart from the faithful restatement.  Each value names one
+// departure from the reference; the cited line is the one the mutant gets wrong.
+enum Mutation {
+  MUT_NONE = 0,
+  MUT_NO_RR_COMPENSATION = 1,   // drops the division by 1 - q            (RayTracer.cpp:277)
+  MUT_NO_MIRROR_HALVING = 2,    // (C + L2) instead of (C + L2) / 2       (RayTracer.cpp:273-274)
+  MUT_SHADOWED_SPECULAR = 3,    // direct specular scaled by the light's visibility (material.cpp:132-143 has no shadow term)
+  MUT_FIXED_SAMPLE_POINT = 4,   // corner + u*uI + v*vI, the intended formula (light.cpp:109 adds vVec whole and vI to all components)
+  MUT_COLOURED_SPECULAR = 5,    // direct specular times the light colour (material.cpp:142 omits it)
+  MUT_SPHERE_NORMAL_FACES_RAY = 6,  // sphere normal flipped toward the ray from inside (Sphere.cpp:33-38 never flips)
+  MUT_COSINE_PDF = 7,           // divides the bounce radiance by 1/pi instead of 1/(2 pi) (RayTracer.cpp:261-263)
+  MUT_CLAMP_AFTER_MEAN = 8,     // no per-sample clamp                    (RayTracer.cpp:54)
+  MUT_ABS_N_DOT_V = 9,          // |n.V| in the specular denominators     (material.cpp:141,160 use the signed value)
+  MUT_SQUARE_NORMAL_FIXED = 10, // square normal always +z                (Square.cpp:33-37 flips it toward the ray)
+  MUT_NO_RR_AT_DEPTH_0 = 11,    // camera-ray hits always survive         (RayTracer.cpp:228-231 applies q at every depth)
+  MUT_ROUGHNESS_AS_ALPHA = 12,  // alpha = roughness instead of its square (material.cpp:103)
+  MUT_NO_INDIRECT_SPECULAR = 13,// drops the indirect specular term       (material.cpp:153-163)
+  MUT_DIFFUSE_IGNORES_METALLIC = 14, // no (1 - metallic) on the diffuse terms (material.cpp:129,149)
+  MUT_FLOAT_FREE_HEMISPHERE = 15,    // hemisphere x, z kept in double    (RayTracer.cpp:248-249 round them to float)
+  MUT_COUNT
+};
+int g_mut = MUT_NONE;
+
 const double RAY_EPSILON = 0.00000001;  // scene/ray.h:147
 
 // ---------------------------------------------------------------- vectors ----
@@ -398,6 +423,7 @@ struct orc_scene {
       i.t = t2;
       i.N = normalize(r.at(t2));
     }
+    if (g_mut == MUT_SPHERE_NORMAL_FACES_RAY && dot(i.N, r.d) > 0) i.N = -i.N;
     return true;
   }
   // Box.cpp:11-74
@@ -446,6 +472,7 @@ struct orc_scene {
     if (P.y < -0.5 || P.y > 0.5) return false;
     i.t = t;
     i.N = d.z > 0.0 ? V3(0.0, 0.0, -1.0) : V3(0.0, 0.0, 1.0);
+    if (g_mut == MUT_SQUARE_NORMAL_FIXED) i.N = V3(0.0, 0.0, 1.0);
     i.u = P.x + 0.5;  // Square.cpp:41
     i.v = P.y + 0.5;
     return true;
@@ -705,6 +732,7 @@ struct orc_scene {
       }
       // samplePoint, light.cpp:105-111: corner + uVec*uI + vVec + vI (vI added to every component)
       V3 position = (L.corner + L.uVec * uI + L.vVec) + V3(vI);
+      if (g_mut == MUT_FIXED_SAMPLE_POINT) position = (L.corner + L.uVec * uI) + L.vVec * vI;
       double lightT = std::sqrt(dot(position - p, position - p));
       Ray sr;
       sr.p = r.p;
@@ -744,6 +772,7 @@ struct orc_scene {
     double roughness = m.roughness();
     if (roughness == 0) roughness = 0.001;
     double alpha = roughness * roughness;
+    if (g_mut == MUT_ROUGHNESS_AS_ALPHA) alpha = roughness;
     double idx = m.index();
     V3 F0 = V3(std::pow((1.0 - idx) / (1.0 + idx), 2));
     double metallic = m.metallic();
@@ -758,28 +787,35 @@ struct orc_scene {
       shadowRay.p = firePos;
       shadowRay.d = lightDirection(L, firePos);
       V3 contributionD = shadowAttenuation((int)li, shadowRay, firePos, prm, rng, key, c);
+      const V3 shadowAtt = contributionD;
       contributionD *= distanceAttenuation(L, P);
       contributionD *= m.kd;
       contributionD *= std::fabs(dot(n, lightDirection(L, P)));
       diffuseTerm += contributionD / M_PI;
-      diffuseTerm *= (1 - metallic);
+      if (g_mut != MUT_DIFFUSE_IGNORES_METALLIC) diffuseTerm *= (1 - metallic);
       diffuseBRDF += diffuseTerm;
       V3 F = fresnel(F0, V, H);
       double D = ndf(alpha, n, H);
       double G = ggxGeometry(n, lightDirection(L, P), alpha) * ggxGeometry(n, V, alpha);
       double nDotl = std::fabs(dot(n, lightDirection(L, P)));
       V3 spec = ((F * D * G) / (4 * nDotl * dot(n, V)));
+      if (g_mut == MUT_ABS_N_DOT_V) spec = ((F * D * G) / (4 * nDotl * std::fabs(dot(n, V))));
+      if (g_mut == MUT_COLOURED_SPECULAR) spec = spec * L.color;
+      if (g_mut == MUT_SHADOWED_SPECULAR) {  // visibility = attenuation over light colour, channel by channel
+        for (int k = 0; k < 3; k++) spec.at(k) *= L.color[k] != 0.0 ? shadowAtt[k] / L.color[k] : 0.0;
+      }
       specularTerm += spec * nDotl * distanceAttenuation(L, P);
     }
     V3 w = -wInDir;
     V3 H = normalize(w + V);
-    diffuseBRDF += (m.kd * indirect) * std::fabs(dot(n, w)) / M_PI * (1 - metallic);
+    diffuseBRDF += (m.kd * indirect) * std::fabs(dot(n, w)) / M_PI * (g_mut == MUT_DIFFUSE_IGNORES_METALLIC ? 1.0 : (1 - metallic));
     V3 F = fresnel(F0, V, H);
     double D = ndf(alpha, n, H);
     double G = ggxGeometry(n, w, alpha) * ggxGeometry(n, V, alpha);
     double nDotl = std::fabs(dot(n, w));
     V3 indirectSpecular = ((F * G * D) / (4 * nDotl * dot(n, V))) * nDotl * indirect;
-    specularTerm += indirectSpecular;
+    if (g_mut == MUT_ABS_N_DOT_V) indirectSpecular = ((F * G * D) / (4 * nDotl * std::fabs(dot(n, V)))) * nDotl * indirect;
+    if (g_mut != MUT_NO_INDIRECT_SPECULAR) specularTerm += indirectSpecular;
     V3 ret = diffuseBRDF;
     ret += ambientTerm;
     ret += specularTerm;
@@ -813,7 +849,7 @@ struct orc_scene {
     if (intersect(r, i, prm.t_max, c)) {
       const Material m = materialAt(i);
       double russianRoulette = rng.draw(key, SLOT_RR);
-      if (russianRoulette < prm.rr_q) return V3(0);
+      if (russianRoulette < prm.rr_q && !(g_mut == MUT_NO_RR_AT_DEPTH_0 && depth == 0)) return V3(0);
       c.shaded++;
       V3 normal = i.N;
       V3 startPos = r.at(i.t);
@@ -829,6 +865,7 @@ struct orc_scene {
       float x = (float)(sinTheta * std::cos(phi));
       float z = (float)(sinTheta * std::sin(phi));
       V3 rd((double)x, r1, (double)z);
+      if (g_mut == MUT_FLOAT_FREE_HEMISPHERE) rd = V3(sinTheta * std::cos(phi), r1, sinTheta * std::sin(phi));
       V3 conv(rd.x * Nb.x + rd.y * normal.x + rd.z * Nt.x, rd.x * Nb.y + rd.y * normal.y + rd.z * Nt.y,
               rd.x * Nb.z + rd.y * normal.z + rd.z * Nt.z);
       conv = normalize(conv);
@@ -836,6 +873,7 @@ struct orc_scene {
       randomRay.p = startPos + conv * RAY_EPSILON;
       randomRay.d = conv;
       double pdf = 1 / (2 * M_PI);
+      if (g_mut == MUT_COSINE_PDF) pdf = 1 / M_PI;
       V3 indirect(0);
       indirect += tracePath(randomRay, depth + 1, mix64(key, SLOT_CHILD_BOUNCE), prm, rng, c);
       indirect /= pdf;
@@ -850,9 +888,9 @@ struct orc_scene {
         reflRay.d = reflDir;
         V3 reflResult = tracePath(reflRay, depth + 1, mix64(key, SLOT_CHILD_MIRROR), prm, rng, c);
         colorC += reflResult;
-        colorC /= 2;
+        if (g_mut != MUT_NO_MIRROR_HALVING) colorC /= 2;
       }
-      colorC /= (1.0 - prm.rr_q);
+      if (g_mut != MUT_NO_RR_COMPENSATION && !(g_mut == MUT_NO_RR_AT_DEPTH_0 && depth == 0)) colorC /= (1.0 - prm.rr_q);
       return colorC;
     }
     if (hasCube) return cubeColor(r.d);
@@ -876,7 +914,7 @@ struct orc_scene {
     for (int k = 0; k < 3; k++) {
       double vv = ret[k];
       if (vv != vv) { nan = true; vv = 0.0; }
-      vv = std::min(std::max(vv, 0.0), 1.0);  // glm::clamp
+      if (g_mut != MUT_CLAMP_AFTER_MEAN) vv = std::min(std::max(vv, 0.0), 1.0);  // glm::clamp
       out.at(k) = vv;
     }
     if (nan) c.nan_samples++;
@@ -907,6 +945,14 @@ struct orc_scene {
 extern "C" {
 
 const char *orc_last_error(void) { return g_err.c_str(); }
+
+// 0 = the faithful restatement; anything else is one of the mutants above (process-wide).
+int orc_set_mutation(int m) {
+  if (m < 0 || m >= MUT_COUNT) return -1;
+  g_mut = m;
+  return 0;
+}
+int orc_mutation_count(void) { return MUT_COUNT; }
 
 double orc_uniform(uint64_t key, uint64_t j) { return u01(mix64(key, j)); }
 uint64_t orc_mix(uint64_t key, uint64_t j) { return mix64(key, j); }

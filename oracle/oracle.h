@@ -86,6 +86,13 @@ int orc_object_order(orc_scene *s, int32_t *order);
 int orc_cubemap_color(orc_scene *s, int64_t n, const double *dir, double *out);
 
 /* Uniform random number j of stream `key` (the counter generator both sides use). */
+/* Mutants of the restatement, for measuring what the published-render pin can detect
+ * (tests/test_reference_screenshots.py): 0 = faithful, 1..orc_mutation_count()-1 each switch
+ * one quirk of the reference off or one common mistake on (the list is in oracle.cpp).
+ * Process-wide. */
+int orc_set_mutation(int m);
+int orc_mutation_count(void);
+
 double orc_uniform(uint64_t key, uint64_t j);
 uint64_t orc_mix(uint64_t key, uint64_t j);
 uint64_t orc_sample_key(uint64_t seed, uint64_t pixel, uint64_t sample);

@@ -216,7 +216,11 @@ int ensure_spill(mipt_ctx *c, uint64_t used, uint64_t extra, hipStream_t st) {
   HIP_TRY(c, hipMalloc(&np, cap * kEntryBytes + 64));
   if (used) {
     launch_copy_rays(carve_queue(c->spill.p, (uint32_t)c->spill_cap), 0, carve_queue(np, (uint32_t)cap), 0, (uint32_t)used, st);
-    HIP_TRY(c, hipStreamSynchronize(st));
+    hipError_t e = hipStreamSynchronize(st);
+    if (e != hipSuccess) {
+      (void)hipFree(np);
+      return set_err(c, MIPT_ERR_DEVICE, "growing the overflow stack: %s", hipGetErrorString(e));
+    }
   }
   if (c->spill.p) HIP_TRY(c, hipFree(c->spill.p));
   c->spill.p = np;
@@ -225,7 +229,7 @@ int ensure_spill(mipt_ctx *c, uint64_t used, uint64_t extra, hipStream_t st) {
   return MIPT_OK;
 }
 
-RenderConst make_const(const mipt_ctx *c, const mipt_params *p, uint32_t capacity) {
+RenderConst make_const(const mipt_ctx *c, const mipt_params *p, uint32_t capacity, uint32_t shade_capacity = 0) {
   RenderConst rc;
   rc.persist_blocks = c->persist_blocks;
   rc.width = p->width;
@@ -237,6 +241,7 @@ RenderConst make_const(const mipt_ctx *c, const mipt_params *p, uint32_t capacit
   rc.seed = p->seed;
   rc.flags = p->flags;
   rc.capacity = capacity;
+  rc.shade_capacity = shade_capacity ? shade_capacity : capacity;
   return rc;
 }
 
@@ -509,16 +514,22 @@ int mipt_upload_scene(mipt_ctx *c, const mipt_scene_desc *desc) {
   return MIPT_OK;
 }
 
-int mipt_render_accumulate(mipt_ctx *c, const mipt_params *p, double *d_sum, void *stream) {
-  if (!c) return set_err(nullptr, MIPT_ERR_INVALID, "null context");
-  if (!c->have_scene) return set_err(c, MIPT_ERR_NOSCENE, "no scene uploaded");
-  int r = check_params(c, p);
-  if (r != MIPT_OK) return r;
-  if (!d_sum) return set_err(c, MIPT_ERR_INVALID, "null d_sum");
-  HIP_TRY(c, hipSetDevice(c->device));
-  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if ((r = sync_lights(c, p->area_samples)) != MIPT_OK) return r;
-  c->dev.t_cap = p->t_max;
+}  // extern "C"
+
+// Device memory one mipt_render_accumulate call works in.  The allocating entry point sizes it
+// for the requested batch and grows the overflow stack on demand; the entry point that may not
+// allocate carves it out of a static device array and fails where the other would grow.
+struct Workspace {
+  void *queue[2], *shade, *hits, *accum, *rows, *counts, *dcount, *vis;
+  uint32_t cap;        // entries per queue / hit record array
+  uint32_t shade_cap;  // entries of the shade list: a launch takes <= batch rays and lists each at most once
+  int64_t batch;       // most samples per wavefront batch (also the most rays one launch takes)
+  uint64_t vis_rays;   // shadow rays the visibility buffer holds (3 doubles each in translucent scenes, else 1)
+  bool may_allocate;   // the overflow stack may grow with hipMalloc, profile events may be created
+};
+
+static int render_core(mipt_ctx *c, const mipt_params *p, double *d_sum, hipStream_t st, const Workspace &ws, const std::vector<int> &rows) {
+  int r;
   bool count = (p->flags & MIPT_FLAG_COUNTERS) != 0;
   bool prof = (p->flags & MIPT_FLAG_PROFILE) != 0;
   // a call that fails half way leaves no half-recorded event pairs behind
@@ -532,51 +543,32 @@ int mipt_render_accumulate(mipt_ctx *c, const mipt_params *p, double *d_sum, voi
     }
   } span_guard{c};
 
-  // rows owned by this shard
-  std::vector<int> rows;
-  for (int j = 0; j < p->height; j++)
-    if ((j / p->band_rows) % p->shard_count == p->shard_index) rows.push_back(j);
   int ns_total = p->sample_end - p->sample_begin;
   int64_t owned = (int64_t)rows.size() * p->width;
-  if (owned == 0 || ns_total == 0) return MIPT_OK;
 
   // batch geometry: SB samples of PB pixels per batch, PB*SB <= B
-  int64_t B = p->batch_samples > 0 ? p->batch_samples : (1ll << 24);
+  const int64_t B = ws.batch;
   int SB = (int)std::min<int64_t>(ns_total, B);
   int64_t PB = std::max<int64_t>(1, B / SB);
   PB = std::min<int64_t>(PB, owned);
-  int64_t batch = PB * SB;
-  if (batch > (1ll << 28)) return set_err(c, MIPT_ERR_LIMIT, "batch_samples too large (limit 2^28)");
-  uint32_t cap = (uint32_t)(2 * batch + 1024);
+  const int64_t batch = PB * SB;
+  const uint32_t cap = ws.cap;
   c->capacity = cap;
-  if ((r = ensure(c, c->queue[0], (size_t)cap * kEntryBytes + 64)) != MIPT_OK) return r;
-  if ((r = ensure(c, c->queue[1], (size_t)cap * kEntryBytes + 64)) != MIPT_OK) return r;
-  if ((r = ensure(c, c->shade, (size_t)cap * kEntryBytes + 64)) != MIPT_OK) return r;
-  if ((r = ensure(c, c->hits, (size_t)cap * (sizeof(double) + sizeof(int)) + 64)) != MIPT_OK) return r;
-  if ((r = ensure(c, c->accum, (size_t)batch * 3 * sizeof(double))) != MIPT_OK) return r;
-  if ((r = ensure(c, c->rows, rows.size() * sizeof(int))) != MIPT_OK) return r;
-  if ((r = ensure(c, c->counts, sizeof(BatchCounts))) != MIPT_OK) return r;
-  // visibility scratch: all shadow rays of a level if they fit 2^31 rays, else chunks of whole hits
   uint64_t rays_per_hit = (uint64_t)std::max(1, c->dev.rays_per_hit);
-  uint64_t vis_rays = std::max<uint64_t>(std::min<uint64_t>((uint64_t)cap * rays_per_hit, 1ull << 31), rays_per_hit);
-  const uint64_t hits_per_chunk = std::min<uint64_t>(vis_rays / rays_per_hit, 0xffffff00ull / rays_per_hit);
-  if ((r = ensure(c, c->vis, vis_rays * sizeof(double) * (c->dev.translucent ? 3 : 1))) != MIPT_OK) return r;
-  if (!c->dcount.p) {
-    if ((r = ensure(c, c->dcount, sizeof(DeviceCounters))) != MIPT_OK) return r;
-    HIP_TRY(c, hipMemset(c->dcount.p, 0, sizeof(DeviceCounters)));
-  }
-  HIP_TRY(c, hipMemcpyAsync(c->rows.p, rows.data(), rows.size() * sizeof(int), hipMemcpyHostToDevice, st));
-  HIP_TRY(c, hipStreamSynchronize(st));  // `rows` is a local vector
+  const uint64_t hits_per_chunk = std::min<uint64_t>(ws.vis_rays / rays_per_hit, 0xffffff00ull / rays_per_hit);
+  HIP_TRY(c, hipMemcpyAsync(ws.rows, rows.data(), rows.size() * sizeof(int), hipMemcpyHostToDevice, st));
+  HIP_TRY(c, hipStreamSynchronize(st));  // `rows` may be gone when the copy runs otherwise
 
-  RenderConst rc = make_const(c, p, cap);
-  RayQueue q[2] = {carve_queue(c->queue[0].p, cap), carve_queue(c->queue[1].p, cap)};
-  ShadeList sl = carve_shade(c->shade.p, cap);
-  double *hit_t = reinterpret_cast<double *>(c->hits.p);
+  RenderConst rc = make_const(c, p, cap, ws.shade_cap);
+  RayQueue q[2] = {carve_queue(ws.queue[0], cap), carve_queue(ws.queue[1], cap)};
+  ShadeList sl = carve_shade(ws.shade, ws.shade_cap);
+  double *hit_t = reinterpret_cast<double *>(ws.hits);
   int *hit_prim = reinterpret_cast<int *>(hit_t + cap);
-  double *accum = reinterpret_cast<double *>(c->accum.p);
-  BatchCounts *bc = reinterpret_cast<BatchCounts *>(c->counts.p);
-  DeviceCounters *dc = reinterpret_cast<DeviceCounters *>(c->dcount.p);
-  const int *d_rows = reinterpret_cast<const int *>(c->rows.p);
+  double *accum = reinterpret_cast<double *>(ws.accum);
+  double *vis = reinterpret_cast<double *>(ws.vis);
+  BatchCounts *bc = reinterpret_cast<BatchCounts *>(ws.counts);
+  DeviceCounters *dc = reinterpret_cast<DeviceCounters *>(ws.dcount);
+  const int *d_rows = reinterpret_cast<const int *>(ws.rows);
   mipt_counters &tot = c->totals;
 
   for (int64_t p0 = 0; p0 < owned; p0 += PB) {
@@ -605,10 +597,11 @@ int mipt_render_accumulate(mipt_ctx *c, const mipt_params *p, double *d_sum, voi
           launch_shade(c->dev, rc, q[cur], n, dup, hit_t, hit_prim, q[cur ^ 1], sl, bc, accum, dc, count, st);
           dup = 1;
         }
+        HIP_TRY(c, hipGetLastError());  // a launch that failed must not read as "the tree ended here"
         BatchCounts h;
         HIP_TRY(c, hipMemcpyAsync(&h, bc, sizeof(h), hipMemcpyDeviceToHost, st));
         HIP_TRY(c, hipStreamSynchronize(st));
-        if (h.overflow || h.next_rays > cap || h.shades > cap)
+        if (h.overflow || h.next_rays > cap || h.shades > ws.shade_cap)
           return set_err(c, MIPT_ERR_DEVICE, "internal error: ray queue overflow (%u rays, capacity %u)", h.next_rays, cap);
         if (count) {
           tot.path_rays += n;
@@ -620,18 +613,23 @@ int mipt_render_accumulate(mipt_ctx *c, const mipt_params *p, double *d_sum, voi
           uint32_t nh = (uint32_t)std::min<uint64_t>(hits_per_chunk, h.shades - h0);
           {
             ProfScope ps(c, prof, MIPT_K_SHADOW, (uint64_t)nh * rays_per_hit, st);
-            launch_shadow_trace(c->dev, rc, sl, h0, nh, reinterpret_cast<double *>(c->vis.p), dc, count, st);
+            launch_shadow_trace(c->dev, rc, sl, h0, nh, vis, dc, count, st);
           }
           {
             ProfScope ps(c, prof, MIPT_K_SHADOW_SUM, nh, st);
-            launch_shadow_sum(c->dev, sl, h0, nh, reinterpret_cast<const double *>(c->vis.p), accum, st);
+            launch_shadow_sum(c->dev, sl, h0, nh, vis, accum, st);
           }
         }
+        HIP_TRY(c, hipGetLastError());
         uint32_t m = h.next_rays;
         cur ^= 1;
         if (m > chunk) {
           // the tree is growing: park the excess on the overflow stack
           uint32_t excess = m - chunk;
+          if (!ws.may_allocate)
+            return set_err(c, MIPT_ERR_LIMIT,
+                           "path tree outgrew the static workspace (%u rays at one level, room for %u): use mipt_render_accumulate or lower max_depth",
+                           m, chunk);
           if ((r = ensure_spill(c, spilled, excess, st)) != MIPT_OK) return r;
           launch_copy_rays(q[cur], chunk, carve_queue(c->spill.p, (uint32_t)c->spill_cap), spilled, excess, st);
           spilled += excess;
@@ -655,6 +653,68 @@ int mipt_render_accumulate(mipt_ctx *c, const mipt_params *p, double *d_sum, voi
   span_guard.done = true;
   HIP_TRY(c, hipGetLastError());
   return MIPT_OK;
+}
+
+// rows of the frame this call's shard owns
+static std::vector<int> owned_rows(const mipt_params *p) {
+  std::vector<int> rows;
+  for (int j = 0; j < p->height; j++)
+    if ((j / p->band_rows) % p->shard_count == p->shard_index) rows.push_back(j);
+  return rows;
+}
+
+extern "C" {
+
+int mipt_render_accumulate(mipt_ctx *c, const mipt_params *p, double *d_sum, void *stream) {
+  if (!c) return set_err(nullptr, MIPT_ERR_INVALID, "null context");
+  if (!c->have_scene) return set_err(c, MIPT_ERR_NOSCENE, "no scene uploaded");
+  int r = check_params(c, p);
+  if (r != MIPT_OK) return r;
+  if (!d_sum) return set_err(c, MIPT_ERR_INVALID, "null d_sum");
+  HIP_TRY(c, hipSetDevice(c->device));
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if ((r = sync_lights(c, p->area_samples)) != MIPT_OK) return r;
+  c->dev.t_cap = p->t_max;
+  std::vector<int> rows = owned_rows(p);
+  int ns_total = p->sample_end - p->sample_begin;
+  int64_t owned = (int64_t)rows.size() * p->width;
+  if (owned == 0 || ns_total == 0) return MIPT_OK;
+
+  Workspace ws;
+  ws.may_allocate = true;
+  ws.batch = p->batch_samples > 0 ? p->batch_samples : (1ll << 24);
+  // the batch the core will form (SB samples of PB pixels, PB*SB <= B) decides the sizes
+  int64_t SB = std::min<int64_t>(ns_total, ws.batch);
+  int64_t PB = std::min<int64_t>(std::max<int64_t>(1, ws.batch / SB), owned);
+  int64_t batch = PB * SB;
+  if (batch > (1ll << 28)) return set_err(c, MIPT_ERR_LIMIT, "batch_samples too large (limit 2^28)");
+  ws.cap = (uint32_t)(2 * batch + 1024);  // a launch takes <= batch rays and every ray has <= 2 children
+  ws.shade_cap = (uint32_t)(batch + 1024);  // the shade list and the visibility buffer are sized by the batch, not by the queues
+  if ((r = ensure(c, c->queue[0], (size_t)ws.cap * kEntryBytes + 64)) != MIPT_OK) return r;
+  if ((r = ensure(c, c->queue[1], (size_t)ws.cap * kEntryBytes + 64)) != MIPT_OK) return r;
+  if ((r = ensure(c, c->shade, (size_t)ws.shade_cap * kEntryBytes + 64)) != MIPT_OK) return r;
+  if ((r = ensure(c, c->hits, (size_t)ws.cap * (sizeof(double) + sizeof(int)) + 64)) != MIPT_OK) return r;
+  if ((r = ensure(c, c->accum, (size_t)batch * 3 * sizeof(double))) != MIPT_OK) return r;
+  if ((r = ensure(c, c->rows, rows.size() * sizeof(int))) != MIPT_OK) return r;
+  if ((r = ensure(c, c->counts, sizeof(BatchCounts))) != MIPT_OK) return r;
+  // visibility scratch: all shadow rays of a level (at most `batch` hits) if they fit 2^31 rays, else chunks of whole hits
+  uint64_t rays_per_hit = (uint64_t)std::max(1, c->dev.rays_per_hit);
+  ws.vis_rays = std::max<uint64_t>(std::min<uint64_t>((uint64_t)(batch + 1024) * rays_per_hit, 1ull << 31), rays_per_hit);
+  if ((r = ensure(c, c->vis, ws.vis_rays * sizeof(double) * (c->dev.translucent ? 3 : 1))) != MIPT_OK) return r;
+  if (!c->dcount.p) {
+    if ((r = ensure(c, c->dcount, sizeof(DeviceCounters))) != MIPT_OK) return r;
+    HIP_TRY(c, hipMemset(c->dcount.p, 0, sizeof(DeviceCounters)));
+  }
+  ws.queue[0] = c->queue[0].p;
+  ws.queue[1] = c->queue[1].p;
+  ws.shade = c->shade.p;
+  ws.hits = c->hits.p;
+  ws.accum = c->accum.p;
+  ws.rows = c->rows.p;
+  ws.counts = c->counts.p;
+  ws.dcount = c->dcount.p;
+  ws.vis = c->vis.p;
+  return render_core(c, p, d_sum, st, ws, rows);
 }
 
 int mipt_resolve(mipt_ctx *c, const double *d_sum, int width, int height, int spp, float *d_rgb_f32, uint8_t *d_rgb8, void *stream) {

@@ -51,7 +51,8 @@ struct RenderConst {
   double t_max;
   uint64_t seed;
   uint32_t flags;
-  uint32_t capacity;  // entries per queue / shade list
+  uint32_t capacity;  // entries per queue
+  uint32_t shade_capacity;  // entries of the shade list
   int persist_blocks; // grid of the persistent traversal kernels (CUs x resident blocks per CU)
 };
 

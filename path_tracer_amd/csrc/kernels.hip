@@ -484,7 +484,7 @@ __global__ void __launch_bounds__(kShadeBlock) k_shade(SceneDev S, RenderConst r
     }
   }
   if (emitShade) {
-    if (is < rc.capacity) {
+    if (is < rc.shade_capacity) {
       sl.px[is] = P.x; sl.py[is] = P.y; sl.pz[is] = P.z;
       sl.nx[is] = N.x; sl.ny[is] = N.y; sl.nz[is] = N.z;
       sl.wx[is] = W.x; sl.wy[is] = W.y; sl.wz[is] = W.z;
