@@ -271,6 +271,22 @@ int mipt_render(mipt_ctx *ctx, const mipt_params *p, float *rgb_f32, uint8_t *rg
  * work is enqueued and its queue sizes are known (it synchronises `stream`). */
 int mipt_render_accumulate(mipt_ctx *ctx, const mipt_params *p, double *d_sum, void *stream);
 
+/* mipt_render_accumulate for callers that cannot allocate device memory (code under HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc).  No counterpart in the
+ * reference.  Same arguments, same result in d_sum; the queues, hit records, per-sample sums and
+ * shadow-ray results live in a static 48 MiB device array instead of buffers sized to the job
+ * (one copy per GPU the library is loaded on, held until the process ends), and the call makes
+ * no hipMalloc / hipFree.  Work proceeds in batches of 2^14 path samples whatever batch_samples
+ * says, so it is slower than the allocating call on large frames.  Limits, reported as
+ * MIPT_ERR_LIMIT: height <= 16384 rows; shadow rays per shaded hit (area_samples per area light
+ * + 1 per other light) <= 65536; the overflow stack for path trees that grow (glossy enclosures)
+ * holds 2^18 rays and cannot be enlarged (the deepest rays are traced first, so a batch parks at
+ * most 2^14 rays per tree level: enough for any tree of depth <= 16, and for deeper ones unless
+ * nearly every hit spawns two rays).  MIPT_FLAG_COUNTERS / MIPT_FLAG_PROFILE are refused
+ * (MIPT_ERR_INVALID).  Every call on one GPU shares that GPU's array: calls that overlap on
+ * one GPU (two contexts, two streams) race; calls on different GPUs do not. */
+int mipt_render_accumulate_static(mipt_ctx *ctx, const mipt_params *p, double *d_sum, void *stream);
+
 /* d_sum / spp -> float image and/or RGB8 image, all device pointers
  * (RayTracer.cpp:75,97-99). */
 int mipt_resolve(mipt_ctx *ctx, const double *d_sum, int width, int height, int spp,

@@ -189,6 +189,7 @@ SIGNATURES = {
     "mipt_upload_scene": (C.c_int, [C.c_void_p, C.POINTER(SceneDesc)]),
     "mipt_render": (C.c_int, [C.c_void_p, C.POINTER(Params), C.c_void_p, C.c_void_p]),
     "mipt_render_accumulate": (C.c_int, [C.c_void_p, C.POINTER(Params), C.c_void_p, C.c_void_p]),
+    "mipt_render_accumulate_static": (C.c_int, [C.c_void_p, C.POINTER(Params), C.c_void_p, C.c_void_p]),
     "mipt_resolve": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mipt_trace_pixel": (C.c_int, [C.c_void_p, C.POINTER(Params), C.c_int, C.c_int, C.POINTER(C.c_double)]),
     "mipt_hit_material": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -28,8 +28,40 @@ struct DevBuf {
 };
 }  // namespace
 
+// ---- static workspace of mipt_render_accumulate_static -------------------------------
+// One file-scope device array per GPU the library is loaded on, held until the process ends.
+// Host code never uses the array's name as an address: mipt_create asks the runtime for the
+// array's device address on its own device (hipGetSymbolAddress) and keeps that pointer in
+// the context; kernels, memsets and copies get the pointer.
+namespace {
+constexpr int64_t kStaticBatch = 1 << 14;                            // path samples per wavefront batch
+constexpr uint64_t kStaticSpill = 1 << 18;                           // ray records the fixed overflow stack holds
+constexpr uint32_t kStaticCap = (uint32_t)(2 * kStaticBatch + 1024);  // queue entries: every ray has <= 2 children
+constexpr uint32_t kStaticShadeCap = (uint32_t)(kStaticBatch + 1024);
+constexpr int kStaticMaxRows = 16384;                                // frame height limit
+constexpr uint32_t kStaticMaxRaysPerHit = 65536;                     // shadow rays per shaded hit (light table entries)
+constexpr size_t kStaticEntryBytes = 10 * sizeof(double) + sizeof(uint32_t) + 1;  // = kEntryBytes below
+constexpr size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+constexpr size_t kOffQueue0 = 0;
+constexpr size_t kOffQueue1 = kOffQueue0 + align256((size_t)kStaticCap * kStaticEntryBytes + 64);
+constexpr size_t kOffShade = kOffQueue1 + align256((size_t)kStaticCap * kStaticEntryBytes + 64);
+constexpr size_t kOffHits = kOffShade + align256((size_t)kStaticShadeCap * kStaticEntryBytes + 64);
+constexpr size_t kOffAccum = kOffHits + align256((size_t)kStaticCap * (sizeof(double) + sizeof(int)) + 64);
+constexpr size_t kOffRows = kOffAccum + align256((size_t)kStaticBatch * 3 * sizeof(double));
+constexpr size_t kOffCounts = kOffRows + align256((size_t)kStaticMaxRows * sizeof(int));
+constexpr size_t kOffDcount = kOffCounts + align256(sizeof(mipt::BatchCounts));
+constexpr size_t kOffRayLight = kOffDcount + align256(sizeof(mipt::DeviceCounters));
+constexpr size_t kOffSpill = kOffRayLight + align256((size_t)kStaticMaxRaysPerHit * sizeof(uint16_t));
+constexpr size_t kOffVis = kOffSpill + align256((size_t)kStaticSpill * kStaticEntryBytes + 64);
+constexpr size_t kStaticBytes = (size_t)48 << 20;                    // 48 MiB in all
+constexpr uint64_t kStaticVisDoubles = (kStaticBytes - kOffVis) / sizeof(double);
+static_assert(kOffVis + ((size_t)16 << 20) <= kStaticBytes, "the visibility buffer needs at least 16 MiB of the static workspace");
+}  // namespace
+static __device__ __align__(256) unsigned char scratch[kStaticBytes];
+
 struct mipt_ctx {
   int device = 0;
+  void *static_ws = nullptr;  // device address of `scratch` on this context's GPU
   std::string err;
   bool have_scene = false;
   HostScene host;  // kept only for its small tables (lights, stats); big arrays are freed after upload
@@ -185,6 +217,7 @@ ShadeList carve_shade(void *base, uint32_t cap) {
   return s;
 }
 constexpr size_t kEntryBytes = 10 * sizeof(double) + sizeof(uint32_t) + 1;  // per queue / shade-list entry
+static_assert(kEntryBytes == kStaticEntryBytes, "the static workspace is laid out for this entry size");
 
 int check_params(mipt_ctx *c, const mipt_params *p) {
   if (!p) return set_err(c, MIPT_ERR_INVALID, "null params");
@@ -310,6 +343,17 @@ int mipt_create(mipt_ctx **out, int device) {
   if (!c) return set_err(nullptr, MIPT_ERR_NOMEM, "out of host memory");
   c->device = device;
   std::memset(&c->dev, 0, sizeof(c->dev));
+  // the static workspace of this GPU: every device holds its own copy of the array at its own address
+  {
+    void *ptr = nullptr;
+    hipError_t se = hipSetDevice(device);
+    if (se == hipSuccess) se = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
+    if (se != hipSuccess) {
+      delete c;
+      return set_err(nullptr, MIPT_ERR_DEVICE, "hipGetSymbolAddress(static workspace) on device %d: %s", device, hipGetErrorString(se));
+    }
+    c->static_ws = ptr;
+  }
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
     c->n_cus = prop.multiProcessorCount;
@@ -525,10 +569,12 @@ struct Workspace {
   uint32_t shade_cap;  // entries of the shade list: a launch takes <= batch rays and lists each at most once
   int64_t batch;       // most samples per wavefront batch (also the most rays one launch takes)
   uint64_t vis_rays;   // shadow rays the visibility buffer holds (3 doubles each in translucent scenes, else 1)
-  bool may_allocate;   // the overflow stack may grow with hipMalloc, profile events may be created
+  bool may_allocate;   // the overflow stack is the context's and grows with hipMalloc; else it is the fixed one below
+  void *spill;         // fixed overflow stack of ray records (used when !may_allocate)
+  uint64_t spill_cap;  // its entries
 };
 
-static int render_core(mipt_ctx *c, const mipt_params *p, double *d_sum, hipStream_t st, const Workspace &ws, const std::vector<int> &rows) {
+static int render_core(mipt_ctx *c, const mipt_params *p, double *d_sum, hipStream_t st, const Workspace &ws, const int *rows, size_t n_rows) {
   int r;
   bool count = (p->flags & MIPT_FLAG_COUNTERS) != 0;
   bool prof = (p->flags & MIPT_FLAG_PROFILE) != 0;
@@ -544,7 +590,7 @@ static int render_core(mipt_ctx *c, const mipt_params *p, double *d_sum, hipStre
   } span_guard{c};
 
   int ns_total = p->sample_end - p->sample_begin;
-  int64_t owned = (int64_t)rows.size() * p->width;
+  int64_t owned = (int64_t)n_rows * p->width;
 
   // batch geometry: SB samples of PB pixels per batch, PB*SB <= B
   const int64_t B = ws.batch;
@@ -556,7 +602,7 @@ static int render_core(mipt_ctx *c, const mipt_params *p, double *d_sum, hipStre
   c->capacity = cap;
   uint64_t rays_per_hit = (uint64_t)std::max(1, c->dev.rays_per_hit);
   const uint64_t hits_per_chunk = std::min<uint64_t>(ws.vis_rays / rays_per_hit, 0xffffff00ull / rays_per_hit);
-  HIP_TRY(c, hipMemcpyAsync(ws.rows, rows.data(), rows.size() * sizeof(int), hipMemcpyHostToDevice, st));
+  HIP_TRY(c, hipMemcpyAsync(ws.rows, rows, n_rows * sizeof(int), hipMemcpyHostToDevice, st));
   HIP_TRY(c, hipStreamSynchronize(st));  // `rows` may be gone when the copy runs otherwise
 
   RenderConst rc = make_const(c, p, cap, ws.shade_cap);
@@ -626,17 +672,21 @@ static int render_core(mipt_ctx *c, const mipt_params *p, double *d_sum, hipStre
         if (m > chunk) {
           // the tree is growing: park the excess on the overflow stack
           uint32_t excess = m - chunk;
-          if (!ws.may_allocate)
+          if (ws.may_allocate) {
+            if ((r = ensure_spill(c, spilled, excess, st)) != MIPT_OK) return r;
+          } else if (spilled + excess > ws.spill_cap) {
             return set_err(c, MIPT_ERR_LIMIT,
-                           "path tree outgrew the static workspace (%u rays at one level, room for %u): use mipt_render_accumulate or lower max_depth",
-                           m, chunk);
-          if ((r = ensure_spill(c, spilled, excess, st)) != MIPT_OK) return r;
-          launch_copy_rays(q[cur], chunk, carve_queue(c->spill.p, (uint32_t)c->spill_cap), spilled, excess, st);
+                           "path tree outgrew the static workspace (%llu rays waiting, room for %llu): use mipt_render_accumulate or lower max_depth",
+                           (unsigned long long)(spilled + excess), (unsigned long long)ws.spill_cap);
+          }
+          RayQueue stack = ws.may_allocate ? carve_queue(c->spill.p, (uint32_t)c->spill_cap) : carve_queue(ws.spill, (uint32_t)ws.spill_cap);
+          launch_copy_rays(q[cur], chunk, stack, spilled, excess, st);
           spilled += excess;
           m = chunk;
         } else if (m < chunk && spilled > 0) {
           uint32_t take = (uint32_t)std::min<uint64_t>(chunk - m, spilled);
-          launch_copy_rays(carve_queue(c->spill.p, (uint32_t)c->spill_cap), spilled - take, q[cur], m, take, st);
+          RayQueue stack = ws.may_allocate ? carve_queue(c->spill.p, (uint32_t)c->spill_cap) : carve_queue(ws.spill, (uint32_t)ws.spill_cap);
+          launch_copy_rays(stack, spilled - take, q[cur], m, take, st);
           spilled -= take;
           m += take;
         }
@@ -682,6 +732,8 @@ int mipt_render_accumulate(mipt_ctx *c, const mipt_params *p, double *d_sum, voi
 
   Workspace ws;
   ws.may_allocate = true;
+  ws.spill = nullptr;
+  ws.spill_cap = 0;
   ws.batch = p->batch_samples > 0 ? p->batch_samples : (1ll << 24);
   // the batch the core will form (SB samples of PB pixels, PB*SB <= B) decides the sizes
   int64_t SB = std::min<int64_t>(ns_total, ws.batch);
@@ -714,7 +766,85 @@ int mipt_render_accumulate(mipt_ctx *c, const mipt_params *p, double *d_sum, voi
   ws.counts = c->counts.p;
   ws.dcount = c->dcount.p;
   ws.vis = c->vis.p;
-  return render_core(c, p, d_sum, st, ws, rows);
+  return render_core(c, p, d_sum, st, ws, rows.data(), rows.size());
+}
+
+int mipt_render_accumulate_static(mipt_ctx *c, const mipt_params *p, double *d_sum, void *stream) {
+  if (!c) return set_err(nullptr, MIPT_ERR_INVALID, "null context");
+  if (!c->have_scene) return set_err(c, MIPT_ERR_NOSCENE, "no scene uploaded");
+  int r = check_params(c, p);
+  if (r != MIPT_OK) return r;
+  if (!d_sum) return set_err(c, MIPT_ERR_INVALID, "null d_sum");
+  if (!c->static_ws) return set_err(c, MIPT_ERR_DEVICE, "the static workspace was not set up for device %d", c->device);
+  if (p->flags & (MIPT_FLAG_COUNTERS | MIPT_FLAG_PROFILE))
+    return set_err(c, MIPT_ERR_INVALID, "MIPT_FLAG_COUNTERS and MIPT_FLAG_PROFILE need mipt_render_accumulate (they keep device counters and events)");
+  if (p->height > kStaticMaxRows)
+    return set_err(c, MIPT_ERR_LIMIT, "frame height %d beyond the static workspace's limit of %d rows", p->height, kStaticMaxRows);
+  HIP_TRY(c, hipSetDevice(c->device));
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  unsigned char *base = static_cast<unsigned char *>(c->static_ws);
+
+  // the per-hit shadow-ray block for this area_samples: light records in place, the ray -> light
+  // table into the workspace (the allocating path keeps its own table and is told to rebuild it)
+  int first = 0;
+  for (LightRec &L : c->lights_host) {
+    L.samples = (L.type == MIPT_LIGHT_RECT_AREA) ? p->area_samples : 1;
+    L.first_ray = first;
+    first += L.samples;
+  }
+  const uint64_t per_ray = c->dev.translucent ? 3 : 1;
+  if ((uint32_t)first > kStaticMaxRaysPerHit || (uint64_t)std::max(first, 1) * per_ray > kStaticVisDoubles)
+    return set_err(c, MIPT_ERR_LIMIT, "%d shadow rays per hit beyond the static workspace's limit of %u", first,
+                   (unsigned)std::min<uint64_t>(kStaticMaxRaysPerHit, kStaticVisDoubles / per_ray));
+  c->lights_area_samples = -1;
+  c->dev.rays_per_hit = first;
+  {
+    uint16_t table[256];  // staged through the stack in pieces: no host allocation either
+    uint16_t *d_table = reinterpret_cast<uint16_t *>(base + kOffRayLight);
+    size_t filled = 0, sent = 0;
+    for (size_t k = 0; k < c->lights_host.size(); k++)
+      for (int s2 = 0; s2 < c->lights_host[k].samples; s2++) {
+        table[filled++] = (uint16_t)k;
+        if (filled == 256) {
+          HIP_TRY(c, hipMemcpy(d_table + sent, table, filled * sizeof(uint16_t), hipMemcpyHostToDevice));
+          sent += filled;
+          filled = 0;
+        }
+      }
+    if (filled) HIP_TRY(c, hipMemcpy(d_table + sent, table, filled * sizeof(uint16_t), hipMemcpyHostToDevice));
+    c->dev.ray_light = d_table;
+  }
+  if (!c->lights_host.empty())
+    HIP_TRY(c, hipMemcpy(const_cast<LightRec *>(c->dev.lights), c->lights_host.data(), c->lights_host.size() * sizeof(LightRec), hipMemcpyHostToDevice));
+  c->dev.t_cap = p->t_max;
+
+  int rows[kStaticMaxRows];  // on the stack: no host allocation either
+  size_t n_rows = 0;
+  for (int j = 0; j < p->height; j++)
+    if ((j / p->band_rows) % p->shard_count == p->shard_index) rows[n_rows++] = j;
+  if (n_rows == 0 || p->sample_end == p->sample_begin) return MIPT_OK;
+
+  Workspace ws;
+  ws.may_allocate = false;
+  ws.batch = kStaticBatch;
+  ws.cap = kStaticCap;
+  ws.shade_cap = kStaticShadeCap;
+  ws.queue[0] = base + kOffQueue0;
+  ws.queue[1] = base + kOffQueue1;
+  ws.shade = base + kOffShade;
+  ws.hits = base + kOffHits;
+  ws.accum = base + kOffAccum;
+  ws.rows = base + kOffRows;
+  ws.counts = base + kOffCounts;
+  ws.dcount = base + kOffDcount;
+  ws.vis = base + kOffVis;
+  ws.vis_rays = kStaticVisDoubles / per_ray;
+  ws.spill = base + kOffSpill;
+  ws.spill_cap = kStaticSpill;
+  // the array keeps the last call's contents: the work counters of the persistent kernels and the
+  // NaN tally start at zero; queues, hit records, sums and visibility are written before they are read
+  HIP_TRY(c, hipMemsetAsync(ws.dcount, 0, sizeof(DeviceCounters), st));
+  return render_core(c, p, d_sum, st, ws, rows, n_rows);
 }
 
 int mipt_resolve(mipt_ctx *c, const double *d_sum, int width, int height, int spp, float *d_rgb_f32, uint8_t *d_rgb8, void *stream) {

@@ -67,6 +67,10 @@ class Context:
         """mipt_render_accumulate into a device buffer of 3*w*h doubles (pointer as int)."""
         self._check(self.lib.mipt_render_accumulate(self._h, C.byref(params), C.c_void_p(d_sum_ptr), C.c_void_p(stream)))
 
+    def render_accumulate_static(self, params: abi.Params, d_sum_ptr: int, stream: int = 0):
+        """mipt_render_accumulate_static: the same work out of the library's static device workspace, no allocation."""
+        self._check(self.lib.mipt_render_accumulate_static(self._h, C.byref(params), C.c_void_p(d_sum_ptr), C.c_void_p(stream)))
+
     def resolve(self, d_sum_ptr: int, width: int, height: int, spp: int, d_f32_ptr: int = 0, d_rgb8_ptr: int = 0, stream: int = 0):
         self._check(self.lib.mipt_resolve(self._h, C.c_void_p(d_sum_ptr), width, height, spp, C.c_void_p(d_f32_ptr or None),
                                           C.c_void_p(d_rgb8_ptr or None), C.c_void_p(stream)))
