@@ -9,10 +9,13 @@ with scene, queues and the radiance sum resident in HBM.  Metric: path samples/s
 (one path sample = one `trace(x, y)` call of the reference, RayTracer.cpp:38-56:
 a camera ray plus its whole tree of bounce, mirror and shadow rays).
 
-With N > 1 (launched by torch.distributed.run, one rank per GPU) every rank renders
-the whole frame for its own slice of the sample range (weak scaling: per-GPU work is
-fixed) and the per-pixel sums are reduced to rank 0 over RCCL once, inside the timed
-region.
+With N > 1 (launched by torch.distributed.run, one rank per GPU) the SAME job is split N
+ways (strong scaling: a step is the same S samples of every pixel whatever N is; every
+rank renders S / N of them for the whole frame, or with --sharding tiles all S for its own
+bands of rows) and the per-pixel sums are brought to rank 0 over RCCL once, inside the
+timed region, where rank 0 also resolves them to the 8-bit frame and copies it to the
+host (what RayTracer::traceImage + getBuffer hand back).  --scaling weak keeps per-GPU
+work fixed instead (every rank renders S samples).
 
 Rank 0 prints one JSON line; see DESIGN.md for how `roofline` and `cpu_baseline`
 are defined.
@@ -31,6 +34,10 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
+INFINITY_CACHE_BYTES = 256 << 20
+# VALU issue roof: 256 CUs x 4 SIMDs, one wave-instruction per 4 cycles and SIMD at 2.4 GHz (the
+# rate at which SQ_ACTIVE_INST_VALU reads "busy": 0.84 busy = 0.84 of this many instructions)
+VALU_PEAK_GINST = 256 * 4 * 2.4 / 4.0
 
 WORKLOADS = {
     # name: (triangles, width, height, area lights, cubemap, nominal spp)
@@ -121,19 +128,25 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="synth1m", choices=sorted(list(WORKLOADS) + list(FIXTURE_WORKLOADS)))
     ap.add_argument("--spp-per-step", type=int, default=0,
-                    help="samples per pixel in one step; 0 = as many as the free HBM allows (128, 64 or 16 at 1080p)")
+                    help="samples per pixel in one step (of the whole job, all ranks together); 0 = as many as the free HBM of one "
+                         "GPU allows (128, 64 or 16 at 1080p)")
     ap.add_argument("--triangles", type=int, default=0)
-    ap.add_argument("--batch-samples", type=int, default=0, help="samples per wavefront batch; 0 = one batch per step")
+    ap.add_argument("--batch-samples", type=int, default=0, help="samples per wavefront batch; 0 = one batch per step and rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     ap.add_argument("--cull-negligible", action="store_true",
                     help="set MIPT_FLAG_CULL_NEGLIGIBLE: skip shadow rays whose whole term is below 2^-52 (off: every shadow "
                          "ray the reference traces is traced)")
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
+                    help="N > 1: 'strong' = the N = 1 job split N ways (default); 'weak' = every rank renders a whole N = 1 step")
     ap.add_argument("--sharding", default="samples", choices=["samples", "tiles"],
-                    help="N > 1: 'samples' = every rank renders the whole frame for its own samples (weak scaling, reduce); "
-                         "'tiles' = every rank renders all samples of its own bands of rows (strong scaling, gather)")
+                    help="N > 1: 'samples' = every rank renders the whole frame for its own samples (reduce); "
+                         "'tiles' = every rank renders all samples of its own bands of rows (gather; strong scaling only)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo rehearses the N>1 path with several ranks on one GPU (RCCL needs one GPU per rank)")
+    ap.add_argument("--max-depth", type=int, default=0, help="0 = the library's default (64)")
+    ap.add_argument("--no-profile-events", action="store_true",
+                    help="time the steps without the per-kernel HIP events (then no kernel_ms_per_step and no roofline)")
     args = ap.parse_args()
 
     import torch
@@ -158,6 +171,11 @@ def main():
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend="gloo")
+    weak = args.scaling == "weak" and world > 1
+    tiles = args.sharding == "tiles" and world > 1
+    if weak and tiles:
+        raise SystemExit("--scaling weak shards the sample range; tiles are a strong-scaling split")
+    mode = "tiles" if tiles else "samples"
 
     scene, w, h, nominal_spp, label = build_scene(args.workload, args.triangles)
     ctx = Context(local_rank)
@@ -166,9 +184,10 @@ def main():
     upload_s = time.time() - t0
     stats = ctx.scene_stats()
 
-    # One step = one batch.  The deep, nearly empty levels of a batch cost the same ~16 ms
-    # whatever its size, so the batch is as large as the free HBM allows (about 700 B per
-    # sample with the shadow-ray scratch); every rank takes the smallest choice of any rank.
+    # One step = S samples of every pixel.  The deep, nearly empty levels of a batch cost the same
+    # ~16 ms whatever its size, so S is as large as the free HBM of one GPU allows (about 700 B per
+    # sample with the shadow-ray scratch); every rank takes the smallest choice of any rank.  S does
+    # not depend on N: with N ranks a step is the same S samples, split N ways (strong scaling).
     S = args.spp_per_step
     if S <= 0:
         free_b = torch.cuda.mem_get_info(local_rank)[0]
@@ -181,20 +200,28 @@ def main():
             if cand * w * h * 700 + (40 << 30) <= free_b and cand * w * h <= (1 << 28):
                 S = cand
                 break
-    batch = args.batch_samples if args.batch_samples > 0 else min(1 << 28, max(1 << 20, S * w * h))
+    if not weak and not tiles and S % world:
+        S = max(world, S - S % world)  # every rank gets the same number of samples
+    step_spp = S * world if weak else S  # samples per pixel one step adds to the frame, all ranks together
+    per_rank_samples = (S if (weak or tiles) else S // world) * w * h
+    batch = args.batch_samples if args.batch_samples > 0 else min(1 << 28, max(1 << 20, per_rank_samples))
     K, W = args.steps, args.warmup
-    tiles = args.sharding == "tiles" and world > 1
-    total_spp = (1 if tiles else world) * (K + W) * S  # the job the steps are slices of
+    total_spp = (K + W + 2) * step_spp  # the job the steps are slices of (+2: the untimed counter and plain steps)
     base = abi.default_params(w, h, spp=total_spp, batch_samples=batch)
-    d_sum = torch.zeros(3 * w * h, dtype=torch.float64, device=f"cuda:{local_rank}")
+    if args.max_depth > 0:
+        base.max_depth = args.max_depth
+    dev = f"cuda:{local_rank}"
+    d_sum = torch.zeros(3 * w * h, dtype=torch.float64, device=dev)
+    d_rgb8 = torch.zeros(3 * w * h, dtype=torch.uint8, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
 
     extra_flags = abi.FLAG_CULL_NEGLIGIBLE if args.cull_negligible else 0
 
     def step_params(step, flags):
-        p = shard_params(base, rank, world, "tiles" if tiles else "samples")
-        first = p.sample_begin + step * S
-        p.sample_begin, p.sample_end = first, first + S
+        whole = abi.default_params(w, h, spp=total_spp, batch_samples=batch)
+        whole.max_depth = base.max_depth
+        whole.sample_begin, whole.sample_end = step * step_spp, (step + 1) * step_spp
+        p = shard_params(whole, rank, world, mode)
         p.flags = flags | extra_flags
         return p
 
@@ -203,64 +230,55 @@ def main():
         if world > 1:
             dist.barrier()
 
+    def finish(spp_done):
+        """The collective, then on rank 0 what traceImage + getBuffer hand back: the 8-bit frame on the host."""
+        full = combine(d_sum, base, mode, dst=0)
+        if rank == 0:
+            ctx.resolve(full.data_ptr(), w, h, spp_done, 0, d_rgb8.data_ptr(), stream)
+            return d_rgb8.cpu()
+        return None
+
     for s in range(W):
         ctx.render_accumulate(step_params(s, 0), d_sum.data_ptr(), stream)
-    if world > 1 and W > 0:
-        # the collective of the timed region, once, untimed: RCCL sets up its channels and
-        # buffers on first use
-        combine(d_sum.clone(), base, "tiles" if tiles else "samples", dst=0)
+    if W > 0:
+        finish(W * step_spp)  # once, untimed: RCCL sets up its channels and buffers on first use
+        d_sum.zero_()
     ctx.reset_counters()
+    prof_flag = 0 if args.no_profile_events else abi.FLAG_PROFILE
     sync()
     t0 = time.perf_counter()
     for s in range(W, W + K):
-        ctx.render_accumulate(step_params(s, abi.FLAG_PROFILE), d_sum.data_ptr(), stream)
-    full = combine(d_sum, base, "tiles" if tiles else "samples", dst=0)
+        ctx.render_accumulate(step_params(s, prof_flag), d_sum.data_ptr(), stream)
+    frame8 = finish(K * step_spp)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ktimes = ctx.kernel_times()
 
-    samples_total = (1 if tiles else world) * K * S * w * h
-    out = None
+    # one more step without the per-kernel events, timed by itself: what the events cost
+    scratch = torch.zeros_like(d_sum)
+    sync()
+    t1 = time.perf_counter()
+    ctx.render_accumulate(step_params(W + K, 0), scratch.data_ptr(), stream)
+    torch.cuda.synchronize()
+    plain_step_ms = (time.perf_counter() - t1) * 1e3
+
+    samples_total = K * step_spp * w * h
     if rank == 0:
         # one instrumented (untimed) step for the work counters; the work is deterministic
         ctx.reset_counters()
-        scratch = torch.zeros_like(d_sum)
-        ctx.render_accumulate(step_params(W, abi.FLAG_COUNTERS), scratch.data_ptr(), stream)
+        scratch.zero_()
+        ctx.render_accumulate(step_params(W + K + 1, abi.FLAG_COUNTERS), scratch.data_ptr(), stream)
         torch.cuda.synchronize()
         cnt = ctx.counters()
         del scratch
-        step_samples = max(1, cnt["samples"])  # rank 0's share of one step (the whole frame unless tiles are sharded)
+        step_samples = max(1, cnt["samples"])  # rank 0's share of one step
         cnt["shaded_records"] = cnt["shadow_rays"] // max(1, scene_rays_per_hit(scene, base.area_samples))
-        dominant = max(("intersect", "shadow"), key=lambda k: ktimes[k]["ms"])
-        kt = ktimes[dominant]
-        bytes_step = algorithmic_bytes(cnt, dominant)
-        launches_step = kt["launches"] / K
-        avg_launch_ms = kt["ms"] / max(1, kt["launches"])
-        achieved = (bytes_step / max(1.0, launches_step)) / (avg_launch_ms * 1e-3) / 1e9 if kt["launches"] else 0.0
-        roofline = {
-            "bound": "hbm",
-            "kernel": "k_shadow_any" if dominant == "shadow" else "k_intersect",
-            "achieved": achieved,
-            "peak": HBM_PEAK_GBS,
-            "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS,
-            "traffic": load_traffic(args.workload, dominant),
-            "traffic_frac": None,  # HBM-side bytes per launch / launch time / peak, filled below
-            "note": "achieved = algorithmic bytes (cache-served for this working set, so frac can pass 1); traffic = HBM-side bytes per launch "
-                    "from the committed rocprofv3 counter passes",
-            "utilisation": load_utilisation(args.workload, dominant),
-            "avg_launch_ms": avg_launch_ms,
-            "launches_per_step": launches_step,
-            "algorithmic_bytes_per_sample": (algorithmic_bytes(cnt, "intersect") + algorithmic_bytes(cnt, "shadow") + 64 * cnt["shaded_hits"]) / step_samples,
-        }
-        if roofline["traffic"] and avg_launch_ms > 0:
-            roofline["traffic_frac"] = roofline["traffic"] / (avg_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
         out = {
             "metric": "path samples/s",
             "value": samples_total / elapsed / 1e6,
@@ -270,13 +288,14 @@ def main():
             "warmup": W,
             "ms_per_step": elapsed / K * 1e3,
             "higher_is_better": True,
-            "scaling": "strong" if tiles else "weak",
+            "scaling": "weak" if weak else "strong",
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
             "config": {
                 "workload": label,
-                "spp_per_step": S,
+                "spp_per_step": step_spp,
+                "spp_per_step_per_rank": S if (weak or tiles) else S // world,
                 "batch_samples": int(batch),
                 "nominal_spp": nominal_spp,
                 "rr_q": base.rr_q,
@@ -285,11 +304,12 @@ def main():
                 "primitives": stats["prims"],
                 "bvh_nodes": stats["nodes"],
                 "scene_bytes": stats["device_bytes"],
-                "sharding": args.sharding if world > 1 else "none",
+                "sharding": mode if world > 1 else "none",
                 "cull_negligible": bool(args.cull_negligible),
+                "timed_region": "K x mipt_render_accumulate + the collective + mipt_resolve to RGB8 + its copy to the host",
             },
-            "roofline": roofline,
-            "kernel_ms_per_step": {k: v["ms"] / K for k, v in ktimes.items()},
+            "frame_checksum": int(frame8.to(torch.int64).sum().item()),
+            "per_kernel_events_cost": {"ms_per_step_with_events": elapsed / K * 1e3, "ms_of_one_step_without": plain_step_ms},
             "per_sample": {
                 "path_rays": cnt["path_rays"] / step_samples,
                 "shadow_rays": cnt["shadow_rays"] / step_samples,
@@ -300,12 +320,17 @@ def main():
             "counters": cnt,
             "mrays_per_s": (cnt["path_rays"] + cnt["shadow_rays"]) / step_samples * samples_total / elapsed / 1e6,
             "scene_upload_s": upload_s,
+            "kernel_source_hash": kernel_source_hash(),
         }
+        if not args.no_profile_events:
+            out["roofline"] = roofline(args.workload, stats["device_bytes"], ktimes, K, cnt, step_samples)
+            out["kernel_ms_per_step"] = {k: v["ms"] / K for k, v in ktimes.items()}
         if world == 1 and not args.no_cpu_baseline:
             cb, p_cpu, img_cpu = cpu_baseline(scene, base, args.cpu_budget)
             out["cpu_baseline"] = cb
             # the same rows on the GPU, same random streams: parity of the bench workload itself
             p_gpu = abi.default_params(w, h, spp=1, band_rows=1, shard_count=p_cpu.shard_count, shard_index=0)
+            p_gpu.max_depth = base.max_depth
             f32, _ = ctx.render(p_gpu, want_f32=True, want_rgb8=False)
             rows = np.arange(0, h, p_cpu.shard_count)
             diff = f32[rows].astype(np.float64) - img_cpu[rows]
@@ -323,35 +348,92 @@ def main():
         dist.destroy_process_group()
 
 
+def kernel_source_hash():
+    from path_tracer_amd.buildinfo import kernel_source_hash as h
+
+    return h()
+
+
 def scene_rays_per_hit(scene, area_samples):
     from path_tracer_amd import abi
 
     return sum(area_samples if L.type == abi.LIGHT_RECT_AREA else 1 for L in scene.lights)
 
 
-def load_traffic(workload, kernel):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC
-    passes (profiles/traffic.json), or None when no measurement for this workload exists."""
-    path = os.path.join(ROOT, "profiles", "traffic.json")
+def load_counters(workload, kernel):
+    """The rocprofv3 counter summary of `kernel` on `workload` (profiles/counters.json, written by
+    tools/make_counters.py from separate --pmc passes over one bench step), or None when there is
+    none or when it was measured on other kernel sources than the ones this run uses."""
     try:
-        with open(path) as fh:
-            t = json.load(fh)
-        return t.get(workload, {}).get("k_shadow_any" if kernel == "shadow" else "k_intersect", {}).get("hbm_bytes_per_launch")
+        with open(os.path.join(ROOT, "profiles", "counters.json")) as fh:
+            entry = json.load(fh).get(workload)
     except (OSError, ValueError):
         return None
+    if not entry or entry.get("kernel_source_hash") != kernel_source_hash():
+        return None
+    return entry.get("kernels", {}).get(kernel)
 
 
-def load_utilisation(workload, kernel):
-    """VALU busy share, VALU lane utilisation, waves per SIMD, TA / TCP busy shares and cache
-    hit rates of the dominant kernel, from the committed rocprofv3 counter passes of this
-    workload (profiles/r01_derived.json, made by tools/derive_metrics.py); None if absent."""
-    if workload != "synth1m":
+def roofline(workload, scene_bytes, ktimes, K, cnt, step_samples):
+    """The roof that binds the dominant kernel (the one with the most device time).
+
+    A scene that fits the 256 MiB Infinity Cache is served on-die: HBM cannot bind, what does is
+    vector-instruction issue (and the vector-L1 path beside it), so `achieved` is VALU
+    wave-instructions per second against CUs x SIMDs x clock / 4; larger scenes are priced
+    against HBM with the algorithmic bytes.  Launch durations are this run's own (HIP events on
+    the launch stream around every launch of the timed steps); instruction counts and HBM-side
+    bytes per launch come from the committed counter passes of the same kernel sources, and are
+    null when the sources have changed since.  The algorithmic-byte rate is always reported as
+    `cache_served_gbs`; it is a roofline fraction only where HBM is the bound."""
+    dominant = max(("intersect", "shadow"), key=lambda k: ktimes[k]["ms"])
+    name = "k_shadow_any" if dominant == "shadow" else "k_intersect"
+    kt = ktimes[dominant]
+    if not kt["launches"]:
         return None
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_derived.json")) as fh:
-            return json.load(fh).get("k_shadow_any" if kernel == "shadow" else "k_intersect")
-    except (OSError, ValueError):
-        return None
+    launches_step = kt["launches"] / K
+    avg_launch_s = kt["ms"] / kt["launches"] * 1e-3
+    alg_bytes_launch = algorithmic_bytes(cnt, dominant) / max(1.0, launches_step)
+    cache_served = alg_bytes_launch / avg_launch_s / 1e9
+    pmc = load_counters(workload, name)
+    traffic = pmc.get("hbm_bytes_per_launch") if pmc else None
+    r = {
+        "kernel": name,
+        "avg_launch_ms": avg_launch_s * 1e3,
+        "launches_per_step": launches_step,
+        "cache_served_gbs": cache_served,
+        "algorithmic_bytes_per_launch": alg_bytes_launch,
+        "algorithmic_bytes_per_sample": (algorithmic_bytes(cnt, "intersect") + algorithmic_bytes(cnt, "shadow") + 64 * cnt["shaded_hits"]) / step_samples,
+        "traffic": traffic,
+        "hbm_frac": traffic / avg_launch_s / 1e9 / HBM_PEAK_GBS if traffic else None,
+        "utilisation": {k: pmc[k] for k in ("valu_busy", "lane_utilisation", "waves_per_simd", "waves_per_simd_compiled", "ta_busy", "tcp_busy",
+                                            "l1_miss_rate", "l2_hit_rate", "wave_time_waiting_on_memory") if k in pmc} if pmc else None,
+        "counters_from": pmc.get("measured") if pmc else None,
+    }
+    if scene_bytes <= INFINITY_CACHE_BYTES:
+        inst = pmc.get("valu_instructions_per_launch") if pmc else None
+        achieved = inst / avg_launch_s / 1e9 if inst else None
+        r.update({
+            "bound": "valu",
+            "achieved": achieved,
+            "peak": VALU_PEAK_GINST,
+            "unit": "G wave-instructions/s",
+            "frac": achieved / VALU_PEAK_GINST if achieved else None,
+            "useful_frac": achieved / VALU_PEAK_GINST * pmc["lane_utilisation"] if achieved and pmc.get("lane_utilisation") else None,
+            "note": "scene fits the Infinity Cache, so vector-instruction issue binds, not HBM: achieved = SQ_INSTS_VALU per launch (counter pass "
+                    "of these kernel sources) / this run's launch time; useful_frac = frac x share of lanes at work; cache_served_gbs = "
+                    "algorithmic bytes / launch time (served by the caches: not a roofline fraction)",
+        })
+    else:
+        r.update({
+            "bound": "hbm",
+            "achieved": cache_served,
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": cache_served / HBM_PEAK_GBS,
+            "note": "scene larger than the Infinity Cache: achieved = algorithmic bytes per launch / launch time against HBM peak; traffic = "
+                    "HBM-side bytes per launch (2 x FETCH_SIZE + WRITE_SIZE) from the counter pass of these kernel sources, hbm_frac = its share of peak",
+        })
+    return r
 
 
 if __name__ == "__main__":
