@@ -54,6 +54,12 @@ bool RayTracer::loadCubemap(const char *dir) {
   return loaded_ ? upload() : true;
 }
 
+void RayTracer::setShard(int index, int count, int band_rows) {
+  params_.shard_index = index;
+  params_.shard_count = count;
+  params_.band_rows = band_rows;
+}
+
 void RayTracer::traceSetup(int w, int h) {
   size_t n = (size_t)w * h * 3;
   buffer_.assign(n, 0);  // std::fill(buffer, 0), RayTracer.cpp:427

@@ -40,6 +40,11 @@ class RayTracer {
   std::array<double, 3> getPixel(int i, int j) const;   // RayTracer.cpp:529-534
   const std::vector<float> &floatBuffer() const { return buffer_f32_; }
 
+  // One process per GPU: this instance renders the bands of rows shard `index` of `count` owns
+  // (band b of `band_rows` rows belongs to shard b % count), as the reference's threads each take a
+  // range of columns (RayTracer.cpp:482-487); the rows of other shards stay as traceSetup left them.
+  void setShard(int index, int count, int band_rows = 8);
+
   // The reference's literals (N = 100, q = 0.1, 10 shadow rays, t < 1000) as settings.
   mipt_params &settings() { return params_; }
   const std::string &lastAlert() const { return alert_; }

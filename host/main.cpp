@@ -8,6 +8,13 @@
 //   -r N     accepted and ignored: the path tracer never reads the recursion depth
 //   -s N     samples per pixel (reference literal: 100)
 //   -d N     HIP device
+// Several GPUs, one process per GPU (any launcher; pin each with -d or HIP_VISIBLE_DEVICES):
+//   --shard I/N    render only the bands of rows that shard I of N owns (band b of --band-rows rows
+//                  belongs to shard b % N, the split mipt_params.shard_* describes); the other rows
+//                  of the output stay black, as traceSetup leaves them (RayTracer.cpp:427)
+//   --band-rows R  rows per band (default 8)
+//   --combine OUT PART...   no rendering: add the shards' .ppm outputs into OUT.  The shards own
+//                  disjoint rows, so the sum is byte for byte the frame one GPU renders
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -15,15 +22,44 @@
 #include <fstream>
 #include <sstream>
 #include <string>
+#include <vector>
 
 #include "RayTracer.h"
 
 static void usage(const char *prog) {
-  std::fprintf(stderr, "usage: %s [-w width] [-H height] [-s spp] [-j settings.json] [-c cubemap_dir] [-d device] [-r depth] scene.json output.png\n", prog);
+  std::fprintf(stderr, "usage: %s [-w width] [-H height] [-s spp] [-j settings.json] [-c cubemap_dir] [-d device] [-r depth] [--shard I/N] [--band-rows R] scene.json output.png\n"
+                       "       %s --combine output.png part0.ppm part1.ppm ...\n", prog, prog);
+}
+
+// --combine: the shards' frames hold disjoint bands of rows and zeros elsewhere
+static int combine(int argc, char **argv) {
+  if (argc < 4) { usage(argv[0]); return 1; }
+  int w = 0, h = 0;
+  std::vector<uint8_t> sum;
+  try {
+    for (int k = 3; k < argc; k++) {
+      int pw = 0, ph = 0;
+      std::vector<uint8_t> part;
+      host::read_ppm(argv[k], &pw, &ph, &part);  // rows bottom-up
+      if (k == 3) { w = pw; h = ph; sum.assign(part.size(), 0); }
+      if (pw != w || ph != h) { std::fprintf(stderr, "%s: %dx%d, expected %dx%d\n", argv[k], pw, ph, w, h); return 1; }
+      for (size_t b = 0; b < sum.size(); b++) {
+        if (part[b] && sum[b]) { std::fprintf(stderr, "%s overlaps an earlier part: the shards must own disjoint rows\n", argv[k]); return 1; }
+        sum[b] = (uint8_t)(sum[b] + part[b]);
+      }
+    }
+  } catch (const std::exception &e) {
+    std::fprintf(stderr, "%s\n", e.what());
+    return 1;
+  }
+  if (!host::write_image(argv[2], w, h, sum.data())) { std::fprintf(stderr, "cannot write %s\n", argv[2]); return 1; }
+  return 0;
 }
 
 int main(int argc, char **argv) {
+  if (argc > 1 && std::string(argv[1]) == "--combine") return combine(argc, argv);
   int width = 512, height = 0, spp = -1, device = 0;
+  int shard_index = 0, shard_count = 1, band_rows = 8;
   std::string settings, cubemap;
   int i = 1;
   for (; i < argc && argv[i][0] == '-' && argv[i][1] != '\0'; i++) {
@@ -39,6 +75,12 @@ int main(int argc, char **argv) {
     else if (opt == "-c") cubemap = need("-c");
     else if (opt == "-d") device = std::atoi(need("-d"));
     else if (opt == "-r") (void)need("-r");
+    else if (opt == "--shard") {
+      if (std::sscanf(need("--shard"), "%d/%d", &shard_index, &shard_count) != 2 || shard_count < 1 || shard_index < 0 || shard_index >= shard_count) {
+        std::fprintf(stderr, "--shard wants I/N with 0 <= I < N\n");
+        return 1;
+      }
+    } else if (opt == "--band-rows") band_rows = std::atoi(need("--band-rows"));
     else if (opt == "-h") { usage(argv[0]); return 0; }
     else { std::fprintf(stderr, "Invalid argument: '%s'.\n", argv[i]); usage(argv[0]); return 1; }
   }
@@ -69,6 +111,7 @@ int main(int argc, char **argv) {
   if (spp > 0) p.spp = spp;
   p.sample_begin = 0;
   p.sample_end = p.spp;
+  rt.setShard(shard_index, shard_count, band_rows);
 
   if (!rt.loadScene(rayName)) {
     std::fprintf(stderr, "Unable to load ray file '%s': %s\n", rayName, rt.lastAlert().c_str());

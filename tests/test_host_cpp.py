@@ -196,3 +196,29 @@ def test_ray_cli_renders_the_same_bytes_as_the_library(scene_file, tmp_path, gpu
     assert np.array_equal(im[::-1], rgb8)
     r = subprocess.run([exe, str(tmp_path / "nope.json"), str(out)], capture_output=True)
     assert r.returncode == 1 and b"Unable to load ray file" in r.stderr
+
+
+@pytest.mark.gpu
+def test_ray_cli_shards_add_up_to_the_single_gpu_frame(scene_file, tmp_path):
+    """One process per GPU from the C++ host: three shards of row bands (here one after the other on one
+    GPU), combined, are byte for byte the unsharded frame."""
+    exe = os.path.join(HOST, "ray")
+    whole = tmp_path / "whole.ppm"
+    common = ["-w", "64", "-H", "44", "-s", "3"]
+    assert subprocess.run([exe] + common + [scene_file, str(whole)], capture_output=True).returncode == 0
+    parts = []
+    for k in range(3):
+        part = tmp_path / f"part{k}.ppm"
+        r = subprocess.run([exe] + common + ["--shard", f"{k}/3", "--band-rows", "4", scene_file, str(part)], capture_output=True)
+        assert r.returncode == 0, r.stderr.decode()
+        parts.append(str(part))
+        img = np.frombuffer(part.read_bytes()[len(b"P6\n64 44\n255\n"):], np.uint8).reshape(44, 64, 3)[::-1]
+        rows = np.arange(44)
+        assert img[(rows // 4) % 3 != k].sum() == 0 and img[(rows // 4) % 3 == k].sum() > 0
+    out = tmp_path / "sum.ppm"
+    r = subprocess.run([exe, "--combine", str(out)] + parts, capture_output=True)
+    assert r.returncode == 0, r.stderr.decode()
+    assert out.read_bytes() == whole.read_bytes()
+    r = subprocess.run([exe, "--combine", str(out), parts[0], parts[0]], capture_output=True)
+    assert r.returncode == 1 and b"overlaps" in r.stderr
+    assert subprocess.run([exe] + common + ["--shard", "3/3", scene_file, str(out)], capture_output=True).returncode == 1

@@ -64,6 +64,7 @@ def main():
     dest = sys.argv[4] if len(sys.argv) > 4 else None
     passes = {p: read_pass(os.path.join(d, p)) for p in ("fetch", "write", "sq1", "sq2", "m1", "m3")}
     ms = {p: (bench_json(os.path.join(d, p + ".json")) or {}).get("kernel_ms_per_step", {}) for p in passes}
+    per_step = {p: (bench_json(os.path.join(d, p + ".json")) or {}).get("kernel_launches_per_step", {}) for p in passes}
     kernels = {}
     for k in sorted(set().union(*[set(v[0]) for v in passes.values()])):
         e = {"measured": tag}
@@ -80,24 +81,30 @@ def main():
             e["hbm_bytes_per_launch"] = (2.0 * e["fetch_size_kib_per_launch"] + e["write_size_kib_per_launch"]) * 1024.0
         if "TCC_HIT_sum" in c and val("TCC_HIT_sum") + val("TCC_MISS_sum") > 0:
             e["l2_hit_rate"] = val("TCC_HIT_sum") / (val("TCC_HIT_sum") + val("TCC_MISS_sum"))
-        cyc = lambda p: ms[p].get(KEY.get(k, ""), 0.0) * 1e-3 * CLOCK  # one step per pass
+        # a pass runs more steps than the timed one (bench.py adds an untimed plain step): the counters sum over all of
+        # them, the event time is per step, so the kernel's cycles are scaled by dispatches / launches per step
+        def cyc(p, counter):
+            key = KEY.get(k, "")
+            lps = per_step[p].get(key, 0.0)
+            steps = c[counter][1] / lps if lps else 1.0
+            return ms[p].get(key, 0.0) * 1e-3 * CLOCK * steps
         if "SQ_INSTS_VALU" in c:
             e["valu_instructions_per_launch"] = val("SQ_INSTS_VALU") / c["SQ_INSTS_VALU"][1]
-            e["valu_instructions"] = val("SQ_INSTS_VALU")
-        if "SQ_ACTIVE_INST_VALU" in c and cyc("sq1") > 0:
-            e["valu_busy"] = val("SQ_ACTIVE_INST_VALU") * 4 / (cyc("sq1") * SIMDS)
+        if "SQ_ACTIVE_INST_VALU" in c and cyc("sq1", "SQ_ACTIVE_INST_VALU") > 0:
+            e["valu_busy"] = val("SQ_ACTIVE_INST_VALU") * 4 / (cyc("sq1", "SQ_ACTIVE_INST_VALU") * SIMDS)
             e["lane_utilisation"] = val("SQ_THREAD_CYCLES_VALU") / (64 * val("SQ_ACTIVE_INST_VALU"))
-            e["waves_per_simd"] = val("SQ_WAVE_CYCLES") * 4 / (cyc("sq1") * SIMDS)
+            e["waves_per_simd"] = val("SQ_WAVE_CYCLES") * 4 / (cyc("sq1", "SQ_WAVE_CYCLES") * SIMDS)
             e["waves_per_simd_compiled"] = 5
             e["kernel_ms_in_counter_pass"] = ms["sq1"].get(KEY.get(k, ""))
         if "SQ_WAIT_ANY" in c and "SQ_WAVE_CYCLES" in c:
             e["wave_time_waiting_on_memory"] = val("SQ_WAIT_ANY") / val("SQ_WAVE_CYCLES")
         if "SQ_INSTS_SALU" in c:
-            e["salu_instructions"] = val("SQ_INSTS_SALU")
-            e["fp64_valu_instructions"] = sum(val(n) or 0.0 for n in ("SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_TRANS_F64"))
-        if "TA_TA_BUSY_sum" in c and cyc("m1") > 0:
-            e["ta_busy"] = val("TA_TA_BUSY_sum") / (CUS * cyc("m1"))
-            e["tcp_busy"] = val("TCP_GATE_EN1_sum") / (CUS * cyc("m1"))
+            nl = c["SQ_INSTS_SALU"][1]
+            e["salu_instructions_per_launch"] = val("SQ_INSTS_SALU") / nl
+            e["fp64_valu_instructions_per_launch"] = sum(val(n) or 0.0 for n in ("SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_TRANS_F64")) / nl
+        if "TA_TA_BUSY_sum" in c and cyc("m1", "TA_TA_BUSY_sum") > 0:
+            e["ta_busy"] = val("TA_TA_BUSY_sum") / (CUS * cyc("m1", "TA_TA_BUSY_sum"))
+            e["tcp_busy"] = val("TCP_GATE_EN1_sum") / (CUS * cyc("m1", "TCP_GATE_EN1_sum"))
         if "TCP_TCC_READ_REQ_sum" in c and val("TCP_TOTAL_CACHE_ACCESSES_sum"):
             e["l1_miss_rate"] = val("TCP_TCC_READ_REQ_sum") / val("TCP_TOTAL_CACHE_ACCESSES_sum")
         kernels[k] = e
