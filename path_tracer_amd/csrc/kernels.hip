@@ -722,6 +722,44 @@ __global__ void __launch_bounds__(kBlock) k_shadow_sum(SceneDev S, ShadeList sl,
   deposit(accum, sl.slot[h], total);
 }
 
+// The same sum with the block's visibility values staged through LDS.  A lane that walks its own
+// hit's rays_per_hit doubles reads 8 bytes of a different cache line with every load, and with
+// tens of waves per CU doing so the lines are evicted between a lane's loads (L1 miss rate 46 %,
+// 1 TB/s).  The values of 256 consecutive hits are one contiguous run of 256 * rays_per_hit
+// doubles: the block copies it to LDS with fully coalesced loads, then every lane sums its hit's
+// values from there.  Opaque scenes with at most four lights and rays_per_hit <= kSumTileRays.
+constexpr int kSumTileRays = 32;
+#ifndef MIPT_SUM_UNTILED
+#define MIPT_SUM_UNTILED 0  // 1: the lane-per-hit kernel for every scene (A/B builds)
+#endif
+__global__ void __launch_bounds__(kBlock) k_shadow_sum_tiled(SceneDev S, ShadeList sl, uint32_t first_hit, uint32_t n_hits,
+                                                              const double *__restrict__ vis, double *accum) {
+  extern __shared__ double vis_tile[];
+  const uint32_t R = (uint32_t)S.rays_per_hit;
+  const uint32_t i0 = blockIdx.x * kBlock;
+  const uint32_t hits_here = min((uint32_t)kBlock, n_hits - i0);
+  const uint32_t n_vals = hits_here * R;
+  const double *src = vis + (uint64_t)i0 * R;
+  for (uint32_t e = threadIdx.x; e < n_vals; e += kBlock) vis_tile[e] = src[e];
+  __syncthreads();
+  if (threadIdx.x >= hits_here) return;
+  const uint32_t h = first_hit + i0 + threadIdx.x;
+  d3 P{sl.px[h], sl.py[h], sl.pz[h]};
+  d3 N{sl.nx[h], sl.ny[h], sl.nz[h]};
+  d3 Wt{sl.wx[h], sl.wy[h], sl.wz[h]};
+  const double *v = vis_tile + threadIdx.x * R;
+  d3 total{0, 0, 0};
+  for (int li = 0; li < S.n_lights; li++) {
+    const LightRec &L = S.lights[li];
+    d3 sum{0, 0, 0};
+    for (int s = 0; s < L.samples; s++) sum = sum + ld3(L.color) * v[L.first_ray + s];
+    if (L.type == MIPT_LIGHT_RECT_AREA) sum = sum / (double)L.samples;  // light.cpp:145
+    double f = distance_attenuation(L, P) * fabs(dot(N, light_direction(L, P)));
+    total = total + (sum * f) * Wt;
+  }
+  deposit(accum, sl.slot[h], total);
+}
+
 // The same sum for scenes with many lights, one lane per (hit, light): a lane-per-hit loop walks
 // rays_per_hit doubles at a stride of rays_per_hit doubles between lanes, which wastes most of
 // every cache line when there are hundreds of rays per hit.  Here adjacent lanes read adjacent
@@ -954,6 +992,11 @@ void launch_shadow_sum(const SceneDev &S, ShadeList sl, uint64_t first_hit, uint
   if (!S.translucent && S.n_lights > 4) {
     hipLaunchKernelGGL(k_shadow_sum_lights, dim3(grid_for((uint64_t)n_hits * (uint64_t)S.n_lights)), dim3(kBlock), 0, st, S, sl, (uint32_t)first_hit,
                        n_hits, vis, accum);
+    return;
+  }
+  if (!S.translucent && S.rays_per_hit <= kSumTileRays && !MIPT_SUM_UNTILED) {
+    hipLaunchKernelGGL(k_shadow_sum_tiled, dim3(grid_for(n_hits)), dim3(kBlock), (size_t)kBlock * S.rays_per_hit * sizeof(double), st, S, sl,
+                       (uint32_t)first_hit, n_hits, vis, accum);
     return;
   }
   auto kern = S.translucent ? k_shadow_sum<true> : k_shadow_sum<false>;
