@@ -1,8 +1,8 @@
-// gpu_build.h — BVH construction on the GPU (linear BVH over Morton codes), the alternative
-// to the host's binned-SAH builder of scene_build.cpp.  Same output format (layout.h: Node4
-// with 8-bit quantised child boxes, primitives in leaf order), built in milliseconds instead
-// of seconds; the trees are of lower quality, so traversal is slower.  Results of the renderer
-// do not depend on the tree (the box tests only cull).
+// gpu_build.h — BVH construction on the GPU (nearest-neighbour clustering of the primitives in
+// Morton order), the alternative to the host's binned-SAH builder of scene_build.cpp.  Same
+// output format (layout.h: Node4 with 8-bit quantised child boxes, primitives in leaf order),
+// built in tens of milliseconds instead of seconds.  Results of the renderer do not depend on
+// the tree (the box tests only cull).
 #ifndef MIPT_GPU_BUILD_H_
 #define MIPT_GPU_BUILD_H_
 
@@ -18,6 +18,7 @@ struct GpuBvh {
   uint32_t *order = nullptr;  // device, n_prims: order[s] = input index of the primitive stored at s; caller frees
   int n_nodes = 0;
   int levels = 0;             // depth of the four-wide tree
+  int rounds = 0;             // clustering rounds the binary tree took
   int n_analytic = 0;         // primitives [0, n_analytic) of the new order are not triangles
 };
 

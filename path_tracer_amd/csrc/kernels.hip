@@ -338,18 +338,128 @@ __global__ void __launch_bounds__(kBlock, MIPT_TRAV_WAVES) k_intersect(SceneDev 
 #define MIPT_SHADE_BLOCK 512
 #endif
 constexpr int kShadeBlock = MIPT_SHADE_BLOCK;
+// One path-tree node (RayTracer::tracePath, RayTracer.cpp:221-306) given the closest hit of its ray:
+// the miss branch, Russian roulette, the bounce and mirror children and the terms of shadeBRDF that
+// need no shadow ray (deposited here); what needs shadow rays is described by (P, N, W).
+struct NodeOut {
+  bool emitBounce, emitMirror, emitShade, shaded;
+  d3 P, N, W;      // hit point, normal, T * kd / pi * (1 - metallic) / norm
+  d3 wdir, rdir;   // bounce and mirror directions
+  d3 Tb, Tm;       // their throughputs
+};
+__device__ __forceinline__ void path_node(const SceneDev &S, const RenderConst &rc, d3 o, d3 d, d3 T, uint64_t key, uint32_t slot, int depth, int prim,
+                                          double t, double *accum, NodeOut &r) {
+  r.emitBounce = r.emitMirror = r.emitShade = r.shaded = false;
+  r.P = r.N = r.W = r.wdir = r.rdir = r.Tb = r.Tm = d3{0, 0, 0};
+  if (prim < 0) {
+    // miss branch, RayTracer.cpp:279-304
+    if (S.has_cubemap) deposit(accum, slot, T * cube_color(S, d));
+    return;
+  }
+  double u0 = u01(mix64(key, SLOT_RR));
+  if (u0 < rc.rr_q) return;  // RayTracer.cpp:228-231
+  r.shaded = true;
+  d3 N = hit_normal(S, prim, o, d);
+  d3 P = o + t * d;  // r.at(i)
+  const ObjRec *ob = S.objects + (S.prim_info[prim] & 0x3fffffffu);
+  const MatRec *m = S.materials + ob->material;
+  d3 kd = ld3(m->kd), ka = ld3(m->ka);
+  if (S.n_textures > 0 && (m->kd_tex | m->ka_tex) != 0) {
+    // texture-mapped colours: MaterialParameter::value at the hit's UV, material.cpp:224-230
+    double tu, tv;
+    hit_uv(S, prim, o, d, tu, tv);
+    if (m->kd_tex > 0) { const TexRec &tx = S.textures[m->kd_tex - 1]; kd = tex_mapped(tx.data, tx.w, tx.h, tu, tv); }
+    if (m->ka_tex > 0) { const TexRec &tx = S.textures[m->ka_tex - 1]; ka = tex_mapped(tx.data, tx.w, tx.h, tu, tv); }
+  }
+  if (S.tri_colors) hit_vertex_color(S, prim, o, d, kd);  // per-vertex colours replace kd, trimesh.cpp:179-189
+  // tangent frame, RayTracer.cpp:236-241
+  d3 Nt;
+  if (fabs(N.x) > fabs(N.y)) Nt = d3{N.z, 0, -N.x} / sqrt(N.x * N.x + N.z * N.z);
+  else Nt = d3{0, -N.z, N.y} / sqrt(N.y * N.y + N.z * N.z);
+  d3 Nb = cross(N, Nt);
+  // hemisphere sample, RayTracer.cpp:244-257 (x and z pass through float)
+  double r1 = u01(mix64(key, SLOT_COS));
+  double sinTheta = sqrt(1 - r1 * r1);
+  double phi = u01(mix64(key, SLOT_PHI)) * 2 * M_PI;
+  double sphi, cphi;
+  sincos(phi, &sphi, &cphi);
+  float xf = (float)(sinTheta * cphi);
+  float zf = (float)(sinTheta * sphi);
+  double rx = (double)xf, rz = (double)zf;
+  d3 wdir = normalize(d3{rx * Nb.x + r1 * N.x + rz * Nt.x, rx * Nb.y + r1 * N.y + rz * Nt.y, rx * Nb.z + r1 * N.z + rz * Nt.z});
+  d3 V = normalize(-d);
+  // shadeBRDF set-up, material.cpp:99-109
+  double roughness = m->roughness;
+  double rB = roughness == 0 ? 0.001 : roughness;
+  double alpha = rB * rB;
+  double f0s = (1.0 - m->index) / (1.0 + m->index);
+  f0s = f0s * f0s;
+  d3 F0{f0s, f0s, f0s};
+  double metallic = m->metallic;
+  if (metallic > 0) F0 = F0 * (1.0 - metallic) + kd * metallic;
+  double nV = dot(N, V);
+  double Gv = ggx_geometry(N, V, alpha);
+  // mirror decision, RayTracer.cpp:268-269 (raw roughness)
+  double u3 = u01(mix64(key, SLOT_MIRROR));
+  bool mirror = roughness < u3;
+  double norm = (1.0 - rc.rr_q) * (mirror ? 2.0 : 1.0);
+  // terms that need no shadow ray: ambient + direct specular, material.cpp:96,132-143
+  d3 A = ka * ld3(S.ambient);
+  double lsum = 0.0;  // sum over lights of the brightest colour channel
+  for (int li = 0; li < S.n_lights; li++) {
+    const LightRec &L = S.lights[li];
+    lsum += fmax(fabs(L.color[0]), fmax(fabs(L.color[1]), fabs(L.color[2])));
+    d3 Ld = light_direction(L, P);
+    d3 H = normalize(Ld + V);
+    d3 F = pow5v(F0, 1 - fabs(dot(V, H)));
+    double D = ndf(alpha, N, H);
+    double G = ggx_geometry(N, Ld, alpha) * Gv;
+    double nl = fabs(dot(N, Ld));
+    d3 spec = ((F * D) * G) / (4 * nl * nV);
+    A = A + (spec * nl) * distance_attenuation(L, P);
+  }
+  deposit(accum, slot, (T * A) / norm);
+  // indirect coefficient, material.cpp:146-163: B = kd*|n.w|/pi*(1-m) + F*G*D/(4*|n.w|*(n.V))*|n.w|
+  {
+    d3 H = normalize(wdir + V);
+    d3 F = pow5v(F0, 1 - fabs(dot(V, H)));
+    double D = ndf(alpha, N, H);
+    double G = ggx_geometry(N, wdir, alpha) * Gv;
+    double nl = fabs(dot(N, wdir));
+    d3 B = (kd * nl) / M_PI * (1 - metallic) + (((F * G) * D) / (4 * nl * nV)) * nl;
+    r.Tb = (T * B) * (2 * M_PI) / norm;  // pdf = 1/(2*pi), RayTracer.cpp:261-263
+  }
+  r.Tm = T / norm;
+  d3 W = ((T * kd) / M_PI * (1 - metallic)) / norm;
+  bool deeper = depth + 1 < rc.max_depth;
+  r.emitBounce = deeper;
+  r.emitMirror = deeper && mirror;
+  r.rdir = d - N * dot(N, d) * 2.0;  // glm::reflect, RayTracer.cpp:270
+  r.emitShade = S.n_lights > 0 && (W.x != 0.0 || W.y != 0.0 || W.z != 0.0);
+  if (r.emitShade && (rc.flags & MIPT_FLAG_CULL_NEGLIGIBLE)) {
+    // every shadow ray of this hit only scales a term bounded by max|W| * sum of the
+    // lights' brightest channels (attenuations and |n.L| are <= 1); below 2^-52 it
+    // cannot move a sample, which lives in [0, 1], by one unit in the last place of 1
+    double wmax = fmax(fabs(W.x), fmax(fabs(W.y), fabs(W.z)));
+    r.emitShade = !(wmax * lsum < 2.220446049250313e-16);
+  }
+  r.P = P;
+  r.N = N;
+  r.W = W;
+  r.wdir = wdir;
+}
+
 template <bool COUNT>
 __global__ void __launch_bounds__(kShadeBlock) k_shade(SceneDev S, RenderConst rc, RayQueue q, uint32_t n, uint32_t dup, const double *__restrict__ hit_t,
                                                    const int *__restrict__ hit_prim, RayQueue nq, ShadeList sl, BatchCounts *bc,
                                                    double *accum, DeviceCounters *dc) {
   uint32_t idx = blockIdx.x * kShadeBlock + threadIdx.x;
   bool live = idx < n;
-  bool emitBounce = false, emitMirror = false, emitShade = false;
-  d3 P{0, 0, 0}, N{0, 0, 0}, W{0, 0, 0}, wdir{0, 0, 0}, rdir{0, 0, 0}, Tb{0, 0, 0}, Tm{0, 0, 0};
+  NodeOut r;
+  r.emitBounce = r.emitMirror = r.emitShade = r.shaded = false;
   uint64_t key = 0;
   uint32_t slot = 0;
   int depth = 0;
-  bool shaded = false;
   if (live) {
     const uint32_t hidx = dup > 1u ? idx - idx % dup : idx;  // the run's traced ray
     int prim = hit_prim[hidx];
@@ -359,101 +469,10 @@ __global__ void __launch_bounds__(kShadeBlock) k_shade(SceneDev S, RenderConst r
     key = q.key[idx];
     slot = q.slot[idx];
     depth = (int)q.depth[idx];
-    if (prim < 0) {
-      // miss branch, RayTracer.cpp:279-304
-      if (S.has_cubemap) deposit(accum, slot, T * cube_color(S, d));
-    } else {
-      double u0 = u01(mix64(key, SLOT_RR));
-      if (!(u0 < rc.rr_q)) {  // RayTracer.cpp:228-231
-        shaded = true;
-        double t = hit_t[hidx];
-        N = hit_normal(S, prim, o, d);
-        P = o + t * d;  // r.at(i)
-        const ObjRec *ob = S.objects + (S.prim_info[prim] & 0x3fffffffu);
-        const MatRec *m = S.materials + ob->material;
-        d3 kd = ld3(m->kd), ka = ld3(m->ka);
-        if (S.n_textures > 0 && (m->kd_tex | m->ka_tex) != 0) {
-          // texture-mapped colours: MaterialParameter::value at the hit's UV, material.cpp:224-230
-          double tu, tv;
-          hit_uv(S, prim, o, d, tu, tv);
-          if (m->kd_tex > 0) { const TexRec &tx = S.textures[m->kd_tex - 1]; kd = tex_mapped(tx.data, tx.w, tx.h, tu, tv); }
-          if (m->ka_tex > 0) { const TexRec &tx = S.textures[m->ka_tex - 1]; ka = tex_mapped(tx.data, tx.w, tx.h, tu, tv); }
-        }
-        if (S.tri_colors) hit_vertex_color(S, prim, o, d, kd);  // per-vertex colours replace kd, trimesh.cpp:179-189
-        // tangent frame, RayTracer.cpp:236-241
-        d3 Nt;
-        if (fabs(N.x) > fabs(N.y)) Nt = d3{N.z, 0, -N.x} / sqrt(N.x * N.x + N.z * N.z);
-        else Nt = d3{0, -N.z, N.y} / sqrt(N.y * N.y + N.z * N.z);
-        d3 Nb = cross(N, Nt);
-        // hemisphere sample, RayTracer.cpp:244-257 (x and z pass through float)
-        double r1 = u01(mix64(key, SLOT_COS));
-        double sinTheta = sqrt(1 - r1 * r1);
-        double phi = u01(mix64(key, SLOT_PHI)) * 2 * M_PI;
-        double sphi, cphi;
-        sincos(phi, &sphi, &cphi);
-        float xf = (float)(sinTheta * cphi);
-        float zf = (float)(sinTheta * sphi);
-        double rx = (double)xf, rz = (double)zf;
-        wdir = normalize(d3{rx * Nb.x + r1 * N.x + rz * Nt.x, rx * Nb.y + r1 * N.y + rz * Nt.y, rx * Nb.z + r1 * N.z + rz * Nt.z});
-        d3 V = normalize(-d);
-        // shadeBRDF set-up, material.cpp:99-109
-        double roughness = m->roughness;
-        double rB = roughness == 0 ? 0.001 : roughness;
-        double alpha = rB * rB;
-        double f0s = (1.0 - m->index) / (1.0 + m->index);
-        f0s = f0s * f0s;
-        d3 F0{f0s, f0s, f0s};
-        double metallic = m->metallic;
-        if (metallic > 0) F0 = F0 * (1.0 - metallic) + kd * metallic;
-        double nV = dot(N, V);
-        double Gv = ggx_geometry(N, V, alpha);
-        // mirror decision, RayTracer.cpp:268-269 (raw roughness)
-        double u3 = u01(mix64(key, SLOT_MIRROR));
-        bool mirror = roughness < u3;
-        double norm = (1.0 - rc.rr_q) * (mirror ? 2.0 : 1.0);
-        // terms that need no shadow ray: ambient + direct specular, material.cpp:96,132-143
-        d3 A = ka * ld3(S.ambient);
-        double lsum = 0.0;  // sum over lights of the brightest colour channel
-        for (int li = 0; li < S.n_lights; li++) {
-          const LightRec &L = S.lights[li];
-          lsum += fmax(fabs(L.color[0]), fmax(fabs(L.color[1]), fabs(L.color[2])));
-          d3 Ld = light_direction(L, P);
-          d3 H = normalize(Ld + V);
-          d3 F = pow5v(F0, 1 - fabs(dot(V, H)));
-          double D = ndf(alpha, N, H);
-          double G = ggx_geometry(N, Ld, alpha) * Gv;
-          double nl = fabs(dot(N, Ld));
-          d3 spec = ((F * D) * G) / (4 * nl * nV);
-          A = A + (spec * nl) * distance_attenuation(L, P);
-        }
-        deposit(accum, slot, (T * A) / norm);
-        // indirect coefficient, material.cpp:146-163: B = kd*|n.w|/pi*(1-m) + F*G*D/(4*|n.w|*(n.V))*|n.w|
-        {
-          d3 H = normalize(wdir + V);
-          d3 F = pow5v(F0, 1 - fabs(dot(V, H)));
-          double D = ndf(alpha, N, H);
-          double G = ggx_geometry(N, wdir, alpha) * Gv;
-          double nl = fabs(dot(N, wdir));
-          d3 B = (kd * nl) / M_PI * (1 - metallic) + (((F * G) * D) / (4 * nl * nV)) * nl;
-          Tb = (T * B) * (2 * M_PI) / norm;  // pdf = 1/(2*pi), RayTracer.cpp:261-263
-        }
-        Tm = T / norm;
-        W = ((T * kd) / M_PI * (1 - metallic)) / norm;
-        bool deeper = depth + 1 < rc.max_depth;
-        emitBounce = deeper;
-        emitMirror = deeper && mirror;
-        rdir = d - N * dot(N, d) * 2.0;  // glm::reflect, RayTracer.cpp:270
-        emitShade = S.n_lights > 0 && (W.x != 0.0 || W.y != 0.0 || W.z != 0.0);
-        if (emitShade && (rc.flags & MIPT_FLAG_CULL_NEGLIGIBLE)) {
-          // every shadow ray of this hit only scales a term bounded by max|W| * sum of the
-          // lights' brightest channels (attenuations and |n.L| are <= 1); below 2^-52 it
-          // cannot move a sample, which lives in [0, 1], by one unit in the last place of 1
-          double wmax = fmax(fabs(W.x), fmax(fabs(W.y), fabs(W.z)));
-          emitShade = !(wmax * lsum < 2.220446049250313e-16);
-        }
-      }
-    }
+    path_node(S, rc, o, d, T, key, slot, depth, prim, prim >= 0 ? hit_t[hidx] : 0.0, accum, r);
   }
+  const bool emitBounce = r.emitBounce, emitMirror = r.emitMirror, emitShade = r.emitShade, shaded = r.shaded;
+  const d3 P = r.P, N = r.N, W = r.W, wdir = r.wdir, rdir = r.rdir, Tb = r.Tb, Tm = r.Tm;
   // ---- compaction: ballots per wave, one atomic per block and counter -----------
   uint32_t ib, im, is;
   block_append3<kShadeBlock>(emitBounce, emitMirror, emitShade, &bc->next_rays, &bc->shades, ib, im, is);

@@ -23,6 +23,10 @@
 namespace mipt {
 namespace {
 
+// Weights of a box's x-, y- and z-facing sides in the builder's surface-area measure: (1, 1, 1) is
+// the plain surface-area heuristic (rays from all directions alike).
+double g_face_weight[3] = {1.0, 1.0, 1.0};
+
 struct D3 {
   double x, y, z;
 };
@@ -113,7 +117,7 @@ struct Box6 {
   double area() const {
     double dx = mx[0] - mn[0], dy = mx[1] - mn[1], dz = mx[2] - mn[2];
     if (dx < 0) return 0;
-    return 2.0 * (dx * dy + dy * dz + dz * dx);
+    return 2.0 * (g_face_weight[2] * (dx * dy) + g_face_weight[0] * (dy * dz) + g_face_weight[1] * (dz * dx));
   }
 };
 
@@ -557,6 +561,12 @@ int build_host_scene(const mipt_scene_desc *d, HostScene *out, std::string *err,
     return fail(MIPT_ERR_INVALID, "null array in scene description");
   if (d->n_objects >= (1 << 30)) return fail(MIPT_ERR_LIMIT, "too many objects (limit 2^30-1)");
 
+  g_face_weight[0] = g_face_weight[1] = g_face_weight[2] = 1.0;
+  if (const char *e = std::getenv("MIPT_SAH_WEIGHTS")) {  // tuning knob: "wx,wy,wz"
+    double w[3];
+    if (std::sscanf(e, "%lf%*[,:]%lf%*[,:]%lf", &w[0], &w[1], &w[2]) == 3 && w[0] > 0 && w[1] > 0 && w[2] > 0)
+      for (int a = 0; a < 3; a++) g_face_weight[a] = w[a];
+  }
   std::memcpy(S.camera.eye, d->camera.eye, sizeof(double) * 3);
   std::memcpy(S.camera.look, d->camera.look, sizeof(double) * 3);
   std::memcpy(S.camera.u, d->camera.u, sizeof(double) * 3);
