@@ -18,6 +18,8 @@ from tests import util as U
 
 pytestmark = pytest.mark.gpu
 
+FRAME_FRAC = 0.998  # share of a frame's pixels that must agree to 1e-5 (tests/test_gpu_parity.py states the same bound)
+
 
 def _rot(rng):
     a, b, c = rng.uniform(0, 2 * math.pi, 3)
@@ -146,4 +148,4 @@ def check_scene(sc, seed, gpu, oracle_lib, n_rays=6000, n_fire=100000, frame=(80
         f32, _ = gpu.render(prm, want_rgb8=False)
         ref = orc.render(prm, threads=8)
         diff = np.abs(f32.astype(np.float64) - ref).max(axis=2)
-        assert (diff <= 1e-5).mean() >= 0.99, f"only {(diff <= 1e-5).mean():.4f} of the pixels within 1e-5 (max {diff.max():.3e})"
+        assert (diff <= 1e-5).mean() >= FRAME_FRAC, f"only {(diff <= 1e-5).mean():.4f} of the pixels within 1e-5 (max {diff.max():.3e})"

@@ -102,7 +102,7 @@ def test_traversal_stack_overflow_area(gpu, oracle_lib, monkeypatch):
     p = abi.default_params(96, 54, spp=2, seed=3)
     f32, rgb8 = gpu.render(p)
     ref, ref8 = orc.render(p, threads=8, want_rgb8=True)
-    assert_images_match(f32, ref, rgb8, ref8, frac=0.995)
+    assert_images_match(f32, ref, rgb8, ref8)
 
 
 def test_gpu_built_bvh_gives_the_same_results(gpu, oracle_lib, monkeypatch):
@@ -128,7 +128,7 @@ def test_gpu_built_bvh_gives_the_same_results(gpu, oracle_lib, monkeypatch):
     p = abi.default_params(96, 54, spp=2, seed=4)
     f32, rgb8 = gpu.render(p)
     ref, ref8 = orc.render(p, threads=8, want_rgb8=True)
-    assert_images_match(f32, ref, rgb8, ref8, frac=0.995)
+    assert_images_match(f32, ref, rgb8, ref8)
 
 
 def test_gpu_built_bvh_is_nearly_as_good_as_the_host_built_one(gpu, monkeypatch):
@@ -221,7 +221,7 @@ def test_translucent_shadow_walk(gpu, oracle_lib):
     pr = abi.default_params(48, 48, spp=2)
     f32, rgb8 = gpu.render(pr)
     ref, ref8 = orc.render(pr, threads=4, want_rgb8=True)
-    assert_images_match(f32, ref, rgb8, ref8, frac=0.995)
+    assert_images_match(f32, ref, rgb8, ref8)
 
 
 # ---------------------------------------------------------------------- images
@@ -267,11 +267,11 @@ def test_mesh_scene_images(gpu, oracle_lib):
     f32, rgb8 = gpu.render(p)
     ref, ref8 = orc.render(p, threads=8, want_rgb8=True)
     assert ref.mean() > 0.02
-    assert_images_match(f32, ref, rgb8, ref8, frac=0.995)
+    assert_images_match(f32, ref, rgb8, ref8)
     p = abi.default_params(96, 54, spp=2)
     f32, rgb8 = gpu.render(p)
     ref, ref8 = orc.render(p, threads=8, want_rgb8=True)
-    assert_images_match(f32, ref, rgb8, ref8, frac=0.995)
+    assert_images_match(f32, ref, rgb8, ref8)
 
 
 def test_cull_negligible_flag_skips_rays_without_changing_the_image(gpu, oracle_lib):
