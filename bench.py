@@ -44,6 +44,8 @@ WORKLOADS = {
     "synth1m": (1_000_000, 1920, 1080, 1, False, 4096),
     "synth10m": (10_000_000, 3840, 2160, 64, True, 8192),
     "synth100k": (100_000, 1920, 1080, 1, False, 4096),
+    # the 1 M scene without the benchmark's rough terrain: glossy ground, path trees multiply (run with --max-depth 8)
+    "synth1m_glossy_terrain": (1_000_000, 1920, 1080, 1, False, 4096),
 }
 FIXTURE_WORKLOADS = {
     # name: (fixture, width, height, nominal spp)
@@ -64,7 +66,7 @@ def build_scene(name, triangles=None):
         tris, w, h, nl, cube, spp = WORKLOADS[name]
         if triangles:
             tris = triangles
-        sc = synth.make_scene(tris, seed=0xC4 if name != "synth10m" else 0xC5, n_area_lights=nl, cubemap=cube)
+        sc = synth.make_scene(tris, seed=0xC4 if name != "synth10m" else 0xC5, n_area_lights=nl, cubemap=cube, rough_terrain=name != "synth1m_glossy_terrain")
         autumn = os.path.join(ROOT, "tests", "golden", "cubemaps", "autumn.npz")
         if cube and os.path.exists(autumn):  # the reference's cubemap_autumn (box-filtered to 128 x 128) instead of the procedural sky
             z = np.load(autumn)

@@ -53,8 +53,14 @@ def _terrain_height(x, z):
     return -2.2 + 0.9 * np.sin(0.35 * x) * np.cos(0.27 * z) + 0.35 * np.sin(1.3 * x + 0.7 * z) + 0.15 * np.cos(2.9 * z - 1.1 * x)
 
 
-def make_scene(n_triangles: int = 1_000_000, seed: int = 0xC4, n_area_lights: int = 1, cubemap: bool = False) -> Scene:
-    """Build the synthetic benchmark scene with about `n_triangles` triangles."""
+def make_scene(n_triangles: int = 1_000_000, seed: int = 0xC4, n_area_lights: int = 1, cubemap: bool = False, rough_terrain: bool = True) -> Scene:
+    """Build the synthetic benchmark scene with about `n_triangles` triangles.
+
+    rough_terrain (the benchmark's choice): the four terrain strips are rough dielectrics
+    (roughness 0.8 / 1.0, metallic 0) whatever the material table says.  With False they keep
+    the table's entries (roughness 0, 0.2, 0.4, 0.6, two of them metallic): every hit on a
+    roughness-0 strip then spawns a mirror ray as well as a bounce ray, and the reference's
+    estimator multiplies rays on the ground (1.8 children per surviving hit)."""
     rng = np.random.RandomState(seed)
     sc = Scene()
     cam = Camera()
@@ -78,7 +84,7 @@ def make_scene(n_triangles: int = 1_000_000, seed: int = 0xC4, n_area_lights: in
         m.metallic = metal[(k // 6 + k) % 3]
         m.index = 1.47
         # terrain strips stay rough dielectrics so that paths do not multiply on the ground
-        if k < 4:
+        if k < 4 and rough_terrain:
             m.roughness, m.metallic = (0.8, 0.0) if k % 2 == 0 else (1.0, 0.0)
         sc.materials.append(m)
 
