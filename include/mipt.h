@@ -222,7 +222,8 @@ typedef struct mipt_counters {
 #define MIPT_K_SHADOW 3
 #define MIPT_K_RESOLVE 4
 #define MIPT_K_SHADOW_SUM 5 /* per-hit sum of the shadow rays' results */
-#define MIPT_K_COUNT 6
+#define MIPT_K_TAIL 6       /* the launch that finishes the deep, nearly empty levels of a path tree */
+#define MIPT_K_COUNT 7
 typedef struct mipt_kernel_times {
   double ms[MIPT_K_COUNT];        /* summed HIP-event durations, milliseconds */
   uint64_t launches[MIPT_K_COUNT];

@@ -14,8 +14,8 @@ FLAG_FIXED_AREA_PATTERN = 1
 FLAG_COUNTERS = 2
 FLAG_PROFILE = 4
 FLAG_CULL_NEGLIGIBLE = 8
-K_GENERATE, K_INTERSECT, K_SHADE, K_SHADOW, K_RESOLVE, K_SHADOW_SUM, K_COUNT = 0, 1, 2, 3, 4, 5, 6
-KERNEL_NAMES = ("generate", "intersect", "shade", "shadow", "resolve", "shadow_sum")
+K_GENERATE, K_INTERSECT, K_SHADE, K_SHADOW, K_RESOLVE, K_SHADOW_SUM, K_TAIL, K_COUNT = 0, 1, 2, 3, 4, 5, 6, 7
+KERNEL_NAMES = ("generate", "intersect", "shade", "shadow", "resolve", "shadow_sum", "tail")
 
 OK, ERR_INVALID, ERR_NOSCENE, ERR_DEVICE, ERR_NOMEM, ERR_LIMIT = 0, -1, -2, -3, -4, -5
 

@@ -79,6 +79,8 @@ struct mipt_ctx {
   DevBuf ray_light;          // light index of every shadow ray of a hit
   int n_cus = 256;
   int persist_blocks = 1536; // CUs x blocks per CU for the persistent traversal kernels
+  uint32_t tail_rays = 0;        // a level with at most this many rays is handed to the tail launch (0: never)
+  long tail_rays_env = -1;       // MIPT_TAIL_RAYS, or -1: chosen per scene at upload
   DevBuf spill;              // overflow stack of ray records (allocated on first use)
   uint64_t spill_cap = 0;    // entries
   mipt_counters totals{};
@@ -343,6 +345,10 @@ int mipt_create(mipt_ctx **out, int device) {
   if (!c) return set_err(nullptr, MIPT_ERR_NOMEM, "out of host memory");
   c->device = device;
   std::memset(&c->dev, 0, sizeof(c->dev));
+  if (const char *e = std::getenv("MIPT_TAIL_RAYS")) {  // tuning knob
+    long v = std::atol(e);
+    if (v >= 0 && v <= (1l << 24)) c->tail_rays_env = v;
+  }
   // the static workspace of this GPU: every device holds its own copy of the array at its own address
   {
     void *ptr = nullptr;
@@ -542,6 +548,10 @@ int mipt_upload_scene(mipt_ctx *c, const mipt_scene_desc *desc) {
     }
   }
   c->n_prims = (int64_t)H.prim_info.size();
+  // The tail launch pays where walks are short and trees deep (the analytic demo scenes: spheres.json
+  // 56.6 -> 51.5 ms per 128 spp, cornellBoxes 157.7 -> 154.1); in mesh scenes its one-ray-per-lane walks cost
+  // more than the few small launches they replace (100 k triangles +1 %, 1 M +3.5 % at 262144 rays), so it is off there.
+  c->tail_rays = c->tail_rays_env >= 0 ? (uint32_t)c->tail_rays_env : (c->n_prims <= 4096 ? (1u << 18) : 0u);
   c->lights_host = H.lights;
   c->lights_area_samples = -1;
   // drop the big host copies
@@ -634,6 +644,22 @@ static int render_core(mipt_ctx *c, const mipt_params *p, double *d_sum, hipStre
       uint32_t dup = (uint32_t)ns;             // the camera rays of a pixel's samples are identical
       while (n > 0) {
         HIP_TRY(c, hipMemsetAsync(bc, 0, sizeof(BatchCounts), st));
+        if (dup == 1 && n <= c->tail_rays && spilled == 0 && !count && (uint64_t)5 * n + 2048 <= cap) {  // the launch hands back < 5 n + 2048 rays
+          // few rays left: one launch follows their trees to the end (or as far as its budget goes)
+          {
+            ProfScope ps(c, prof, MIPT_K_TAIL, n, st);
+            launch_tail(c->dev, rc, q[cur], n, q[cur ^ 1], bc, accum, st);
+          }
+          HIP_TRY(c, hipGetLastError());
+          BatchCounts ht;
+          HIP_TRY(c, hipMemcpyAsync(&ht, bc, sizeof(ht), hipMemcpyDeviceToHost, st));
+          HIP_TRY(c, hipStreamSynchronize(st));
+          if (ht.overflow || ht.next_rays > cap)
+            return set_err(c, MIPT_ERR_DEVICE, "internal error: ray queue overflow in the tail launch (%u rays, capacity %u)", ht.next_rays, cap);
+          n = ht.next_rays;
+          cur ^= 1;
+          continue;
+        }
         {
           ProfScope ps(c, prof, MIPT_K_INTERSECT, n, st);
           launch_intersect(c->dev, rc, q[cur], n, dup, hit_t, hit_prim, dc, count, st);

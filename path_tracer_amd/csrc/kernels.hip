@@ -817,6 +817,219 @@ __global__ void __launch_bounds__(kBlock) k_shadow_sum_lights(SceneDev S, ShadeL
   if (live && (lane == 0u || pi != i)) deposit(accum, sl.slot[h], c);
 }
 
+// -------------------------------------------------------------------- tail ----
+// The deep levels of a path tree hold few rays: a level of a few thousand rays costs four
+// launches whose duration is the latency of their longest walk, and there can be fifty such
+// levels.  When a level is down to `tail` rays the rest of the tree is finished by ONE launch:
+// every wave follows its rays depth first.  A lane takes a ray, finds its closest hit, evaluates
+// the path node (path_node), traces the node's shadow rays itself, one after the other, and
+// hands the node's children to its wave's stack in LDS, from which the lanes of that wave take
+// their next rays (last in, first out, so the stack stays shallow).  No wave waits for another.
+// A wave that has worked through kTailBudget rounds, or whose stack is full, hands what it holds
+// (its stack, its lanes' rays, its untouched input) to the output queue and ends; the host then
+// goes on with those (another tail launch, or ordinary levels).  A wave hands back at most
+// kTailStack + 128 rays beyond its input, so a launch of n rays emits fewer than 5 n + 2048.
+// A sample's direct term is added ray by ray here, hit by hit in k_shadow_sum: the sums differ by
+// the rounding of fp64 additions in another order.
+constexpr int kTailStack = 96;       // pending rays per wave
+constexpr int kTailBudget = 4096;    // rounds (nodes per lane) a wave works before it hands its stack back
+struct TailWaveStack {
+  double v[9][kTailStack];  // origin, direction, throughput
+  uint64_t key[kTailStack];
+  uint32_t slot[kTailStack];
+  uint32_t depth[kTailStack];
+  // the shaded hits of the current round, whose shadow rays the wave's lanes share out
+  double hit[9][64];  // P, N, W
+  uint64_t hit_key[64];
+  uint32_t hit_slot[64];
+};
+
+template <bool WALK, bool LOCAL>
+__global__ void __launch_bounds__(kBlock, 2) k_tail(SceneDev S, RenderConst rc, RayQueue q, uint32_t n, RayQueue nq, BatchCounts *bc, double *accum) {
+  extern __shared__ uint32_t lds_stack[];
+  __shared__ TailWaveStack pend_all[kBlock / 64];
+  const Stack stack{lds_stack + threadIdx.x, kBlock, blockIdx.x * kBlock + threadIdx.x};
+  TailWaveStack &pend = pend_all[threadIdx.x / 64];
+  const uint32_t lane = lane_id();
+  const uint32_t wave = blockIdx.x * (kBlock / 64) + threadIdx.x / 64;
+  const uint32_t n_waves = gridDim.x * (kBlock / 64);
+  TravCounters tc{0, 0};
+  uint32_t top = 0;                 // entries on the wave's stack (wave-uniform)
+  bool stop = false;                // wave-uniform: out of budget or out of stack, hand everything back
+  uint64_t next_in = (uint64_t)wave * 64ull;  // next input ray of this wave's current chunk
+  uint32_t in_left = 64;            // rays of that chunk not yet taken
+  bool active = false;
+  d3 o{0, 0, 0}, d{0, 0, 1}, T{0, 0, 0};
+  uint64_t key = 0;
+  uint32_t slot = 0;
+  int depth = 0;
+  // appends this lane's ray to the output queue (a wave-aggregated reservation)
+  auto emit_out = [&](bool mine, d3 eo, d3 ed, d3 eT, uint64_t ekey, uint32_t eslot, int edepth) {
+    unsigned long long m = __ballot(mine);
+    if (m == 0ull) return;
+    uint32_t base = 0;
+    if (lane == (uint32_t)__ffsll((long long)m) - 1u) base = atomicAdd(&bc->next_rays, (uint32_t)__popcll(m));
+    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)__shfl((int)base, __ffsll((long long)m) - 1));
+    if (mine) {
+      uint32_t i = base + rank_below(m, lane);
+      if (i < rc.capacity) {
+        nq.ox[i] = eo.x; nq.oy[i] = eo.y; nq.oz[i] = eo.z;
+        nq.dx[i] = ed.x; nq.dy[i] = ed.y; nq.dz[i] = ed.z;
+        nq.tx[i] = eT.x; nq.ty[i] = eT.y; nq.tz[i] = eT.z;
+        nq.key[i] = ekey;
+        nq.slot[i] = eslot;
+        nq.depth[i] = (uint8_t)edepth;
+      } else {
+        bc->overflow = 1;
+      }
+    }
+  };
+  // pushes this lane's ray on the wave's stack, or to the output queue when the stack is full
+  auto push = [&](bool mine, d3 eo, d3 ed, d3 eT, uint64_t ekey, uint32_t eslot, int edepth) {
+    unsigned long long m = __ballot(mine);
+    if (m == 0ull) return;
+    uint32_t i = top + rank_below(m, lane);
+    bool fits = mine && i < (uint32_t)kTailStack;
+    if (fits) {
+      pend.v[0][i] = eo.x; pend.v[1][i] = eo.y; pend.v[2][i] = eo.z;
+      pend.v[3][i] = ed.x; pend.v[4][i] = ed.y; pend.v[5][i] = ed.z;
+      pend.v[6][i] = eT.x; pend.v[7][i] = eT.y; pend.v[8][i] = eT.z;
+      pend.key[i] = ekey;
+      pend.slot[i] = eslot;
+      pend.depth[i] = (uint32_t)edepth;
+    }
+    emit_out(mine && !fits, eo, ed, eT, ekey, eslot, edepth);
+    if (top + (uint32_t)__popcll(m) > (uint32_t)kTailStack) stop = true;  // at most 64 rays per wave leave this way: the wave ends its work
+    top = min(top + (uint32_t)__popcll(m), (uint32_t)kTailStack);
+  };
+  for (int round = 0;; round++) {
+    // ---- lanes without a ray take one: from the wave's stack first, then from the input ----
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    unsigned long long idle = __ballot(!active);
+    if (idle != 0ull && top > 0 && !stop) {
+      uint32_t take = min((uint32_t)__popcll(idle), top);
+      uint32_t r = rank_below(idle, lane);
+      if (!active && r < take) {
+        uint32_t i = top - 1u - r;
+        o = d3{pend.v[0][i], pend.v[1][i], pend.v[2][i]};
+        d = d3{pend.v[3][i], pend.v[4][i], pend.v[5][i]};
+        T = d3{pend.v[6][i], pend.v[7][i], pend.v[8][i]};
+        key = pend.key[i];
+        slot = pend.slot[i];
+        depth = (int)pend.depth[i];
+        active = true;
+      }
+      top -= take;
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      idle = __ballot(!active);
+    }
+    while (idle != 0ull && next_in < (uint64_t)n && !stop) {
+      uint32_t avail = (uint32_t)min((uint64_t)in_left, (uint64_t)n - next_in);
+      uint32_t take = min((uint32_t)__popcll(idle), avail);
+      uint32_t r = rank_below(idle, lane);
+      if (!active && r < take) {
+        uint64_t i = next_in + r;
+        o = d3{q.ox[i], q.oy[i], q.oz[i]};
+        d = d3{q.dx[i], q.dy[i], q.dz[i]};
+        T = d3{q.tx[i], q.ty[i], q.tz[i]};
+        key = q.key[i];
+        slot = q.slot[i];
+        depth = (int)q.depth[i];
+        active = true;
+      }
+      next_in += take;
+      in_left -= take;
+      if (in_left == 0u || next_in >= (uint64_t)n) {  // on to this wave's next chunk
+        next_in = next_in - (next_in % 64ull == 0ull ? 64ull : next_in % 64ull) + (uint64_t)n_waves * 64ull;
+        in_left = 64;
+      }
+      idle = __ballot(!active);
+    }
+    if (__ballot(active) == 0ull) {
+      if (stop) {
+        // out of budget with rays left: hand the stack and this wave's untouched input back
+        for (uint32_t b = 0; b < top; b += 64u) {
+          uint32_t i = b + lane;
+          bool mine = i < top;
+          uint32_t k = mine ? i : 0u;
+          emit_out(mine, d3{pend.v[0][k], pend.v[1][k], pend.v[2][k]}, d3{pend.v[3][k], pend.v[4][k], pend.v[5][k]},
+                   d3{pend.v[6][k], pend.v[7][k], pend.v[8][k]}, pend.key[k], pend.slot[k], (int)pend.depth[k]);
+        }
+        while (next_in < (uint64_t)n) {
+          uint32_t avail = (uint32_t)min((uint64_t)in_left, (uint64_t)n - next_in);
+          bool mine = lane < avail;
+          uint64_t k = mine ? next_in + lane : 0ull;
+          emit_out(mine, d3{q.ox[k], q.oy[k], q.oz[k]}, d3{q.dx[k], q.dy[k], q.dz[k]}, d3{q.tx[k], q.ty[k], q.tz[k]}, q.key[k], q.slot[k], (int)q.depth[k]);
+          next_in = next_in - next_in % 64ull + (uint64_t)n_waves * 64ull;
+          in_left = 64;
+        }
+      }
+      break;
+    }
+    // ---- one path node per lane ------------------------------------------------------
+    NodeOut r;
+    r.emitBounce = r.emitMirror = r.emitShade = r.shaded = false;
+    if (active) {
+      Hit h = traverse<false, false, LOCAL>(S, o, d, rc.t_max, stack, tc);
+      path_node(S, rc, o, d, T, key, slot, depth, h.prim, h.prim >= 0 ? h.t : 0.0, accum, r);
+    }
+    // ---- the direct diffuse term (material.cpp:111-130): the shadow rays of the round's shaded hits,
+    // dealt out over all 64 lanes (a wave that is down to a few long paths would otherwise trace each
+    // hit's rays one after the other on one lane) ----
+    {
+      const bool shade = active && r.emitShade;
+      const unsigned long long sm = __ballot(shade);
+      const uint32_t n_shade = (uint32_t)__popcll(sm);
+      if (n_shade) {
+        if (shade) {
+          const uint32_t k = rank_below(sm, lane);
+          pend.hit[0][k] = r.P.x; pend.hit[1][k] = r.P.y; pend.hit[2][k] = r.P.z;
+          pend.hit[3][k] = r.N.x; pend.hit[4][k] = r.N.y; pend.hit[5][k] = r.N.z;
+          pend.hit[6][k] = r.W.x; pend.hit[7][k] = r.W.y; pend.hit[8][k] = r.W.z;
+          pend.hit_key[k] = key;
+          pend.hit_slot[k] = slot;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t R = (uint32_t)S.rays_per_hit, items = n_shade * R;
+        for (uint32_t it = lane; it < items; it += 64u) {
+          const uint32_t k = it / R, ray = it - k * R;
+          const int li = light_of_ray(S, ray);
+          const LightRec &L = S.lights[li];
+          d3 P{pend.hit[0][k], pend.hit[1][k], pend.hit[2][k]};
+          d3 N{pend.hit[3][k], pend.hit[4][k], pend.hit[5][k]};
+          d3 W{pend.hit[6][k], pend.hit[7][k], pend.hit[8][k]};
+          d3 fire = P + (N * MIPT_RAY_EPSILON) * 3.0;  // material.cpp:117
+          d3 v = shadow_ray<false, WALK, LOCAL>(S, rc, L, li, (int)ray - L.first_ray, fire, pend.hit_key[k], stack, tc);
+          if (L.type == MIPT_LIGHT_RECT_AREA) v = v / (double)L.samples;  // light.cpp:145
+          double f = distance_attenuation(L, P) * fabs(dot(N, light_direction(L, P)));
+          deposit(accum, pend.hit_slot[k], (v * f) * W);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+    // ---- children: the bounce ray stays with the lane, the mirror ray goes to the stack ----
+    const bool bounce = active && r.emitBounce, mirror = active && r.emitMirror;
+    push(mirror, r.P + MIPT_RAY_EPSILON * r.N, r.rdir, r.Tm, mix64(key, SLOT_CHILD_MIRROR), slot, depth + 1);  // RayTracer.cpp:270-271
+    if (bounce) {
+      o = r.P + r.wdir * MIPT_RAY_EPSILON;  // RayTracer.cpp:259
+      d = r.wdir;
+      T = r.Tb;
+      key = mix64(key, SLOT_CHILD_BOUNCE);
+      depth = depth + 1;
+    }
+    active = bounce;
+    if (round + 1 >= kTailBudget) stop = true;
+    if (stop) {  // the lanes' own rays go back too
+      emit_out(active, o, d, T, key, slot, depth);
+      active = false;
+    }
+  }
+}
+
 // ----------------------------------------------------------------- resolve ----
 __global__ void __launch_bounds__(kBlock) k_resolve(RenderConst rc, const double *__restrict__ accum, const int *__restrict__ rows,
                                                      int64_t first_pixel, int n_pixels, int n_samples, double *d_sum, DeviceCounters *dc) {
@@ -1020,6 +1233,14 @@ void launch_shadow_sum(const SceneDev &S, ShadeList sl, uint64_t first_hit, uint
   }
   auto kern = S.translucent ? k_shadow_sum<true> : k_shadow_sum<false>;
   hipLaunchKernelGGL(kern, dim3(grid_for(n_hits)), dim3(kBlock), 0, st, S, sl, (uint32_t)first_hit, n_hits, vis, accum);
+}
+
+// Grid of the tail kernel: one lane per input ray, at most the two blocks per CU it is compiled for.
+void launch_tail(const SceneDev &S, const RenderConst &rc, RayQueue q, uint32_t n, RayQueue next, BatchCounts *bc, double *accum, hipStream_t st) {
+  if (!n) return;
+  uint64_t full = (n + kBlock - 1) / kBlock, cap = (uint64_t)rc.persist_blocks;  // persist_blocks >= CUs, within the stack overflow area
+  auto kern = S.local_meshes ? (S.translucent ? k_tail<true, true> : k_tail<false, true>) : (S.translucent ? k_tail<true, false> : k_tail<false, false>);
+  hipLaunchKernelGGL(kern, dim3((unsigned)(full < cap ? full : cap)), dim3(kBlock), stack_bytes(S), st, S, rc, q, n, next, bc, accum);
 }
 
 void launch_resolve(const RenderConst &rc, const double *accum, const int *rows, int64_t first_pixel, int n_pixels, int n_samples,
