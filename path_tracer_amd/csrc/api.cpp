@@ -83,6 +83,14 @@ struct mipt_ctx {
   long tail_rays_env = -1;       // MIPT_TAIL_RAYS, or -1: chosen per scene at upload
   DevBuf spill;              // overflow stack of ray records (allocated on first use)
   uint64_t spill_cap = 0;    // entries
+  // Second launch stream: the shadow rays of a level run on it beside the next level's closest-hit
+  // launch on the caller's stream.  Kernels on it get their own stack overflow area and their own
+  // persistent-kernel work counters (the second DeviceCounters of `dcount`).
+  hipStream_t shadow_stream = nullptr;
+  hipEvent_t summed[2] = {nullptr, nullptr};  // per half of the shade list: its last reader on the shadow stream is done
+  uint32_t *stack_ovf_b = nullptr;
+  bool overlap = true;       // MIPT_OVERLAP=0 keeps every launch on the caller's stream
+  uint32_t overlap_rays = 1u << 18;  // levels with at most this many rays use the second stream (MIPT_OVERLAP_RAYS)
   mipt_counters totals{};
 
   // MIPT_FLAG_PROFILE: event pairs recorded around kernel launches, resolved after
@@ -216,6 +224,14 @@ ShadeList carve_shade(void *base, uint32_t cap) {
   s.wx = d + 6ull * cap; s.wy = d + 7ull * cap; s.wz = d + 8ull * cap;
   s.key = reinterpret_cast<uint64_t *>(d + 9ull * cap);
   s.slot = reinterpret_cast<uint32_t *>(d + 10ull * cap);
+  return s;
+}
+ShadeList offset_shade(ShadeList s, uint32_t first) {  // the list that starts at entry `first` of `s`
+  s.px += first; s.py += first; s.pz += first;
+  s.nx += first; s.ny += first; s.nz += first;
+  s.wx += first; s.wy += first; s.wz += first;
+  s.key += first;
+  s.slot += first;
   return s;
 }
 constexpr size_t kEntryBytes = 10 * sizeof(double) + sizeof(uint32_t) + 1;  // per queue / shade-list entry
@@ -363,6 +379,19 @@ int mipt_create(mipt_ctx **out, int device) {
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
     c->n_cus = prop.multiProcessorCount;
+  if (const char *e = std::getenv("MIPT_OVERLAP")) c->overlap = std::atoi(e) != 0;  // measurement knobs
+  if (const char *e = std::getenv("MIPT_OVERLAP_RAYS")) {
+    long v = std::atol(e);
+    if (v >= 0 && v <= (1l << 30)) c->overlap_rays = (uint32_t)v;
+  }
+  if (c->overlap) {
+    hipError_t se = hipStreamCreateWithFlags(&c->shadow_stream, hipStreamNonBlocking);
+    for (int k = 0; k < 2 && se == hipSuccess; k++) se = hipEventCreateWithFlags(&c->summed[k], hipEventDisableTiming);
+    if (se != hipSuccess) {
+      mipt_destroy(c);
+      return set_err(nullptr, MIPT_ERR_DEVICE, "second launch stream on device %d: %s", device, hipGetErrorString(se));
+    }
+  }
   *out = c;
   return MIPT_OK;
 }
@@ -383,6 +412,9 @@ void mipt_destroy(mipt_ctx *c) {
   release(c->vis);
   release(c->ray_light);
   for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
+  for (hipEvent_t e : c->summed)
+    if (e) (void)hipEventDestroy(e);
+  if (c->shadow_stream) (void)hipStreamDestroy(c->shadow_stream);
   delete c;
 }
 
@@ -530,6 +562,13 @@ int mipt_upload_scene(mipt_ctx *c, const mipt_scene_desc *desc) {
     c->scene_allocs.push_back(p);
     c->scene_bytes += (int64_t)bytes;
     D.stack_ovf = reinterpret_cast<uint32_t *>(p);
+    c->stack_ovf_b = nullptr;
+    if (c->overlap) {  // kernels of the two streams run side by side and number their threads alike
+      HIP_TRY(c, hipMalloc(&p, bytes));
+      c->scene_allocs.push_back(p);
+      c->scene_bytes += (int64_t)bytes;
+      c->stack_ovf_b = reinterpret_cast<uint32_t *>(p);
+    }
   }
   D.translucent = H.translucent ? 1 : 0;
   D.local_meshes = H.local_meshes ? 1 : 0;
@@ -618,6 +657,29 @@ static int render_core(mipt_ctx *c, const mipt_params *p, double *d_sum, hipStre
   RenderConst rc = make_const(c, p, cap, ws.shade_cap);
   RayQueue q[2] = {carve_queue(ws.queue[0], cap), carve_queue(ws.queue[1], cap)};
   ShadeList sl = carve_shade(ws.shade, ws.shade_cap);
+
+  // Two launch streams for the narrow levels.  A level with few rays cannot fill the chip: its
+  // launches last as long as one ray's walk (50-150 us), whatever their size.  The shadow rays of
+  // level k (shadow trace + sum) depend on k_shade(k) only, and the closest-hit launch of level
+  // k + 1 does not depend on them, so on such levels they run on the context's second stream while
+  // the caller's stream goes on with level k + 1.  What the two share is the shade list: these
+  // levels alternate between its halves, and k_shade waits for the last shadow launch that read
+  // the half it is about to fill; the per-sample accumulators take atomic adds from both sides.
+  // Not with the work counters (one set), and not in the entry point that may not allocate (its
+  // workspace has one stack overflow area).
+  const bool overlap = c->overlap && c->shadow_stream && c->stack_ovf_b && ws.may_allocate && !count;
+  SceneDev dev_b = c->dev;
+  if (overlap) dev_b.stack_ovf = c->stack_ovf_b;
+  const uint32_t half = (ws.shade_cap / 2) & ~63u;  // keeps the second half's arrays aligned like the first's
+  bool reading[2] = {false, false};  // summed[k] marks the end of a shadow launch that reads half k
+  int side = 0;
+  struct ShadowStreamGuard {  // no return leaves work behind on the second stream
+    hipStream_t s;
+    bool on;
+    ~ShadowStreamGuard() {
+      if (on) (void)hipStreamSynchronize(s);
+    }
+  } shadow_guard{c->shadow_stream, overlap};
   double *hit_t = reinterpret_cast<double *>(ws.hits);
   int *hit_prim = reinterpret_cast<int *>(hit_t + cap);
   double *accum = reinterpret_cast<double *>(ws.accum);
@@ -664,16 +726,29 @@ static int render_core(mipt_ctx *c, const mipt_params *p, double *d_sum, hipStre
           ProfScope ps(c, prof, MIPT_K_INTERSECT, n, st);
           launch_intersect(c->dev, rc, q[cur], n, dup, hit_t, hit_prim, dc, count, st);
         }
+        // where this level's shaded hits go: the whole list, or (two streams, few enough rays) one half of it
+        // (wide levels fill the chip by themselves and only lose by sharing it: they stay on one stream)
+        const bool halves = overlap && n <= half && n <= c->overlap_rays;
+        hipStream_t sb = halves ? c->shadow_stream : st;
+        if (halves) side ^= 1;
+        const uint32_t sl_off = halves && side ? half : 0u;
+        RenderConst rc_l = rc;
+        if (halves) rc_l.shade_capacity = half;
+        if (overlap) {
+          for (int k = 0; k < 2; k++)
+            if (reading[k] && (!halves || k == side)) HIP_TRY(c, hipStreamWaitEvent(st, c->summed[k], 0));
+        }
+        ShadeList sl_l = offset_shade(sl, sl_off);
         {
           ProfScope ps(c, prof, MIPT_K_SHADE, n, st);
-          launch_shade(c->dev, rc, q[cur], n, dup, hit_t, hit_prim, q[cur ^ 1], sl, bc, accum, dc, count, st);
+          launch_shade(c->dev, rc_l, q[cur], n, dup, hit_t, hit_prim, q[cur ^ 1], sl_l, bc, accum, dc, count, st);
           dup = 1;
         }
         HIP_TRY(c, hipGetLastError());  // a launch that failed must not read as "the tree ended here"
         BatchCounts h;
         HIP_TRY(c, hipMemcpyAsync(&h, bc, sizeof(h), hipMemcpyDeviceToHost, st));
         HIP_TRY(c, hipStreamSynchronize(st));
-        if (h.overflow || h.next_rays > cap || h.shades > ws.shade_cap)
+        if (h.overflow || h.next_rays > cap || h.shades > rc_l.shade_capacity)
           return set_err(c, MIPT_ERR_DEVICE, "internal error: ray queue overflow (%u rays, capacity %u)", h.next_rays, cap);
         if (count) {
           tot.path_rays += n;
@@ -681,16 +756,26 @@ static int render_core(mipt_ctx *c, const mipt_params *p, double *d_sum, hipStre
           tot.shadow_rays += (uint64_t)h.shades * (uint64_t)c->dev.rays_per_hit;
         }
         // shadow rays of this level, in chunks of whole hits that fit the visibility buffer
+        // (the caller's stream has been synchronised since k_shade: the second stream needs no event to start)
+        if (overlap && !halves && h.shades) {  // back on one stream: the visibility buffer may still be in use on the other
+          for (int k = 0; k < 2; k++)
+            if (reading[k]) HIP_TRY(c, hipStreamWaitEvent(st, c->summed[k], 0));
+          reading[0] = reading[1] = false;
+        }
         for (uint64_t h0 = 0; h0 < h.shades; h0 += hits_per_chunk) {
           uint32_t nh = (uint32_t)std::min<uint64_t>(hits_per_chunk, h.shades - h0);
           {
-            ProfScope ps(c, prof, MIPT_K_SHADOW, (uint64_t)nh * rays_per_hit, st);
-            launch_shadow_trace(c->dev, rc, sl, h0, nh, vis, dc, count, st);
+            ProfScope ps(c, prof, MIPT_K_SHADOW, (uint64_t)nh * rays_per_hit, sb);
+            launch_shadow_trace(halves ? dev_b : c->dev, rc, sl_l, h0, nh, vis, halves ? dc + 1 : dc, count, sb);
           }
           {
-            ProfScope ps(c, prof, MIPT_K_SHADOW_SUM, nh, st);
-            launch_shadow_sum(c->dev, sl, h0, nh, vis, accum, st);
+            ProfScope ps(c, prof, MIPT_K_SHADOW_SUM, nh, sb);
+            launch_shadow_sum(c->dev, sl_l, h0, nh, vis, accum, sb);
           }
+        }
+        if (halves && h.shades) {
+          HIP_TRY(c, hipEventRecord(c->summed[side], sb));
+          reading[side] = true;
         }
         HIP_TRY(c, hipGetLastError());
         uint32_t m = h.next_rays;
@@ -717,6 +802,10 @@ static int render_core(mipt_ctx *c, const mipt_params *p, double *d_sum, hipStre
           m += take;
         }
         n = m;
+      }
+      if (overlap) {  // the batch's last shadow sums land before its samples are resolved
+        for (int k = 0; k < 2; k++)
+          if (reading[k]) HIP_TRY(c, hipStreamWaitEvent(st, c->summed[k], 0));
       }
       {
         ProfScope ps(c, prof, MIPT_K_RESOLVE, (uint64_t)npix, st);
@@ -780,8 +869,8 @@ int mipt_render_accumulate(mipt_ctx *c, const mipt_params *p, double *d_sum, voi
   ws.vis_rays = std::max<uint64_t>(std::min<uint64_t>((uint64_t)(batch + 1024) * rays_per_hit, 1ull << 31), rays_per_hit);
   if ((r = ensure(c, c->vis, ws.vis_rays * sizeof(double) * (c->dev.translucent ? 3 : 1))) != MIPT_OK) return r;
   if (!c->dcount.p) {
-    if ((r = ensure(c, c->dcount, sizeof(DeviceCounters))) != MIPT_OK) return r;
-    HIP_TRY(c, hipMemset(c->dcount.p, 0, sizeof(DeviceCounters)));
+    if ((r = ensure(c, c->dcount, 2 * sizeof(DeviceCounters))) != MIPT_OK) return r;  // the second one: work counters of the shadow stream
+    HIP_TRY(c, hipMemset(c->dcount.p, 0, 2 * sizeof(DeviceCounters)));
   }
   ws.queue[0] = c->queue[0].p;
   ws.queue[1] = c->queue[1].p;

@@ -13,7 +13,7 @@ import math
 import numpy as np
 import pytest
 
-from path_tracer_amd import abi
+from path_tracer_amd import abi, synth
 from tests import util as U
 from tests.conftest import SCENE_NAMES
 
@@ -424,6 +424,29 @@ def test_growing_path_trees_spill_to_the_overflow_stack(gpu, oracle_lib):
     ref, cnt = orc.render(p, threads=8, want_counters=True)
     assert cnt["path_rays"] > 40 * 16 * 16 * 2                        # the tree really grew
     assert_images_match(f32, ref)
+
+
+def test_two_launch_streams_give_the_one_stream_frame(scenes, monkeypatch):
+    # narrow levels put their shadow rays on a second stream beside the next level's closest-hit
+    # launch; MIPT_OVERLAP=0 keeps everything on the caller's stream.  Same rays, same sums up to
+    # the order of the atomic adds into a sample's accumulator.
+    from path_tracer_amd.raytracer import Context
+    frames = {}
+    for knob, rays in (("0", "0"), ("1", "1073741824"), ("1", "4096")):   # one stream; every level that fits a half list; narrow levels only
+        monkeypatch.setenv("MIPT_OVERLAP", knob)
+        monkeypatch.setenv("MIPT_OVERLAP_RAYS", rays)
+        ctx = Context(0)
+        try:
+            for name in ("cornellBoxes", "areaLight", "mesh"):
+                ctx.upload_scene(synth.make_scene(20000, seed=3) if name == "mesh" else scenes(name))
+                for batch in (0, 3000):                                   # one batch; many small ones with spills and refills
+                    p = abi.default_params(96, 96, spp=6, seed=21, batch_samples=batch)
+                    frames.setdefault((name, batch), []).append(ctx.render(p, want_rgb8=False)[0].astype(np.float64))
+        finally:
+            ctx.close()
+    for key, (one, every, narrow) in frames.items():
+        assert one.max() > 0.05, key
+        assert np.abs(every - one).max() <= 1e-6 and np.abs(narrow - one).max() <= 1e-6, key  # float32 frames: an ulp at most
 
 
 # ------------------------------------------------------------------ edge cases
