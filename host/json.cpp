@@ -9,6 +9,8 @@ namespace {
 struct Reader {
   const std::string &s;
   size_t i = 0;
+  int depth = 0;  // open arrays and objects: bounded, a scene nests a few dozen levels at most
+  static constexpr int kMaxDepth = 512;
   explicit Reader(const std::string &t) : s(t) {}
 
   [[noreturn]] void fail(const char *what) const { throw JsonError(std::string("JSON: ") + what + " at offset " + std::to_string(i)); }
@@ -34,8 +36,13 @@ struct Reader {
     ws();
     if (i >= s.size()) fail("unexpected end");
     char c = s[i];
-    if (c == '{') return object();
-    if (c == '[') return array();
+    if (c == '{' || c == '[') {
+      if (depth >= kMaxDepth) fail("nested too deeply");
+      depth++;
+      Json j = c == '{' ? object() : array();
+      depth--;
+      return j;
+    }
     if (c == '"') {
       Json j;
       j.type = Json::String;

@@ -171,6 +171,9 @@ def test_cpp_loader_reports_errors(host_bins, tmp_path):
     bad.write_text('[{"sphere": {}')
     assert subprocess.run([exe, str(bad)], capture_output=True).returncode == 2
     assert subprocess.run([exe, str(tmp_path / "missing.json")], capture_output=True).returncode == 2
+    bad.write_text("[" * 200000)  # nesting is bounded: an error, not a stack overflow
+    r = subprocess.run([exe, str(bad)], capture_output=True)
+    assert r.returncode == 2 and b"nested too deeply" in r.stderr
 
 
 @pytest.mark.gpu
