@@ -567,6 +567,9 @@ int build_host_scene(const mipt_scene_desc *d, HostScene *out, std::string *err,
     if (std::sscanf(e, "%lf%*[,:]%lf%*[,:]%lf", &w[0], &w[1], &w[2]) == 3 && w[0] > 0 && w[1] > 0 && w[2] > 0)
       for (int a = 0; a < 3; a++) g_face_weight[a] = w[a];
   }
+  auto finite3 = [](const double *v) { return std::isfinite(v[0]) && std::isfinite(v[1]) && std::isfinite(v[2]); };
+  if (!finite3(d->camera.eye) || !finite3(d->camera.look) || !finite3(d->camera.u) || !finite3(d->camera.v))
+    return fail(MIPT_ERR_INVALID, "camera vectors are not finite");
   std::memcpy(S.camera.eye, d->camera.eye, sizeof(double) * 3);
   std::memcpy(S.camera.look, d->camera.look, sizeof(double) * 3);
   std::memcpy(S.camera.u, d->camera.u, sizeof(double) * 3);
@@ -627,8 +630,12 @@ int build_host_scene(const mipt_scene_desc *d, HostScene *out, std::string *err,
     if (src.type == MIPT_OBJ_TRIMESH && (src.mesh < 0 || src.mesh >= d->n_meshes)) return fail(MIPT_ERR_INVALID, "object mesh index out of range");
     ObjRec &o = S.objects[k];
     std::memset(&o, 0, sizeof(o));
+    for (int e = 0; e < 16; e++)
+      if (!std::isfinite(src.xform[e])) return fail(MIPT_ERR_INVALID, "object transform is not finite");
     double inv[16];
     if (!invert4(src.xform, inv)) return fail(MIPT_ERR_INVALID, "singular object transform");
+    for (int e = 0; e < 16; e++)
+      if (!std::isfinite(inv[e])) return fail(MIPT_ERR_INVALID, "singular object transform");
     for (int r = 0; r < 3; r++)
       for (int c = 0; c < 4; c++) o.inv[4 * r + c] = M(inv, r, c);
     if (!normal_matrix(src.xform, o.normi)) return fail(MIPT_ERR_INVALID, "singular object transform");
@@ -666,6 +673,7 @@ int build_host_scene(const mipt_scene_desc *d, HostScene *out, std::string *err,
         mn = mx = D3{m.vertices[0], m.vertices[1], m.vertices[2]};  // trimesh.h:75-90
         for (int64_t v = 0; v < m.n_vertices; v++) {
           D3 p{m.vertices[3 * v], m.vertices[3 * v + 1], m.vertices[3 * v + 2]};
+          if (!(std::isfinite(p.x) && std::isfinite(p.y) && std::isfinite(p.z))) return fail(MIPT_ERR_INVALID, "mesh vertex is not finite");
           mn = {std::min(mn.x, p.x), std::min(mn.y, p.y), std::min(mn.z, p.z)};
           mx = {std::max(mx.x, p.x), std::max(mx.y, p.y), std::max(mx.z, p.z)};
         }
@@ -682,6 +690,11 @@ int build_host_scene(const mipt_scene_desc *d, HostScene *out, std::string *err,
       // an empty mesh has an empty box in the reference; it can never be hit
       for (int a = 0; a < 3; a++) { wb.mn[a] = 0; wb.mx[a] = 0; }
     }
+    // the builder's binning and the 8-bit box quantisation need coordinates they can do arithmetic on
+    // (a NaN vertex makes every comparison false; products of coordinates beyond 1e100 overflow)
+    for (int a = 0; a < 3; a++)
+      if (!(std::fabs(wb.mn[a]) <= 1e100 && std::fabs(wb.mx[a]) <= 1e100))
+        return fail(MIPT_ERR_INVALID, "object coordinates are not finite (or beyond 1e100)");
     for (int a = 0; a < 3; a++) { objBoxes[6 * k + a] = wb.mn[a]; objBoxes[6 * k + 3 + a] = wb.mx[a]; }
   }
 

@@ -7,6 +7,7 @@
 // Prints "ok <scenes>" and exits 0, or describes the first violation and exits 1.
 #include <cmath>
 #include <cstdio>
+#include <limits>
 #include <cstdlib>
 #include <random>
 #include <string>
@@ -152,7 +153,38 @@ static int check_scene(unsigned seed, int nTris, int nSpheres, double extent) {
   return 0;
 }
 
+// Coordinates the builder cannot do arithmetic on are refused at the boundary, not built into a tree.
+static int check_refusals() {
+  const double nan = std::numeric_limits<double>::quiet_NaN(), inf = std::numeric_limits<double>::infinity();
+  const double bads[] = {nan, inf, -inf, 1e308};
+  for (int which = 0; which < 3; which++)
+    for (double bad : bads) {
+      std::vector<double> verts = {0, 0, 0, 1, 0, 0, 0, 1, 0, 2, 2, 2, 3, 2, 2, 2, 3, 2};
+      std::vector<int32_t> faces = {0, 1, 2, 3, 4, 5};
+      mipt_material mat{};
+      mat.roughness = 1; mat.index = 1;
+      mipt_object o{};
+      o.type = MIPT_OBJ_TRIMESH; o.material = 0; o.mesh = 0;
+      o.xform[0] = o.xform[5] = o.xform[10] = o.xform[15] = 1;
+      mipt_mesh mesh{verts.data(), 6, faces.data(), 2, nullptr};
+      mipt_scene_desc d{};
+      d.camera.look[2] = -1; d.camera.u[0] = 1; d.camera.v[1] = 1;
+      d.materials = &mat; d.n_materials = 1;
+      d.objects = &o; d.n_objects = 1;
+      d.meshes = &mesh; d.n_meshes = 1;
+      if (which == 0) verts[10] = bad;
+      if (which == 1) o.xform[13] = bad;
+      if (which == 2) d.camera.eye[1] = bad;
+      if (which == 2 && bad == 1e308) continue;  // a finite camera position is the caller's business
+      HostScene S;
+      std::string err;
+      if (build_host_scene(&d, &S, &err) != MIPT_ERR_INVALID || err.empty()) return fail("non-finite input was not refused", which);
+    }
+  return 0;
+}
+
 int main() {
+  if (check_refusals()) return 1;
   int scenes = 0;
   struct Case { int tris, spheres; double extent; };
   const Case cases[] = {{0, 0, 1}, {0, 1, 1}, {1, 0, 1}, {2, 0, 5}, {3, 2, 5}, {17, 0, 1}, {64, 5, 10}, {500, 0, 1e-3}, {500, 3, 1e4}, {3000, 7, 40}};
