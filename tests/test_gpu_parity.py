@@ -490,6 +490,22 @@ def test_errors_are_reported_not_swallowed(scenes):
     broken.objects[0].material = 99
     with pytest.raises(MiptError):
         ctx.upload_scene(broken)
+    # coordinates no tree can be built from are refused at upload, and the context stays usable
+    from path_tracer_amd import synth
+    mesh_scene = synth.make_scene(2000, seed=5)
+    for bad in (float("nan"), float("inf"), 1e300):
+        broken = copy.deepcopy(mesh_scene)
+        broken.meshes[0].vertices[3, 1] = bad
+        with pytest.raises(MiptError) as e:
+            ctx.upload_scene(broken)
+        assert e.value.code == abi.ERR_INVALID
+    broken = copy.deepcopy(mesh_scene)
+    broken.objects[0].xform[0, 3] = float("nan")
+    with pytest.raises(MiptError):
+        ctx.upload_scene(broken)
+    ctx.upload_scene(mesh_scene)
+    f32, _ = ctx.render(abi.default_params(16, 16, spp=2), want_rgb8=False)
+    assert np.isfinite(f32).all() and f32.max() > 0
     with pytest.raises(MiptError):
         Context(4096)
     ctx.close()
