@@ -91,6 +91,8 @@ struct mipt_ctx {
   uint32_t *stack_ovf_b = nullptr;
   bool overlap = true;       // MIPT_OVERLAP=0 keeps every launch on the caller's stream
   uint32_t overlap_rays = 1u << 18;  // levels with at most this many rays use the second stream (MIPT_OVERLAP_RAYS)
+  uint32_t fuse_rays = 0;            // mesh scenes: a level with at most this many rays is followed to the end by one launch that
+  long fuse_rays_env = -1;           // exports its shaded hits to the shadow kernels (MIPT_FUSE_RAYS, or -1: chosen at upload)
   mipt_counters totals{};
 
   // MIPT_FLAG_PROFILE: event pairs recorded around kernel launches, resolved after
@@ -380,6 +382,10 @@ int mipt_create(mipt_ctx **out, int device) {
   if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
     c->n_cus = prop.multiProcessorCount;
   if (const char *e = std::getenv("MIPT_OVERLAP")) c->overlap = std::atoi(e) != 0;  // measurement knobs
+  if (const char *e = std::getenv("MIPT_FUSE_RAYS")) {
+    long v = std::atol(e);
+    if (v >= 0 && v <= (1l << 24)) c->fuse_rays_env = v;
+  }
   if (const char *e = std::getenv("MIPT_OVERLAP_RAYS")) {
     long v = std::atol(e);
     if (v >= 0 && v <= (1l << 30)) c->overlap_rays = (uint32_t)v;
@@ -591,6 +597,7 @@ int mipt_upload_scene(mipt_ctx *c, const mipt_scene_desc *desc) {
   // 56.6 -> 51.5 ms per 128 spp, cornellBoxes 157.7 -> 154.1); in mesh scenes its one-ray-per-lane walks cost
   // more than the few small launches they replace (100 k triangles +1 %, 1 M +3.5 % at 262144 rays), so it is off there.
   c->tail_rays = c->tail_rays_env >= 0 ? (uint32_t)c->tail_rays_env : (c->n_prims <= 4096 ? (1u << 18) : 0u);
+  c->fuse_rays = c->fuse_rays_env >= 0 ? (uint32_t)c->fuse_rays_env : (c->n_prims > 4096 ? (1u << 17) : 0u);
   c->lights_host = H.lights;
   c->lights_area_samples = -1;
   // drop the big host copies
@@ -710,7 +717,7 @@ static int render_core(mipt_ctx *c, const mipt_params *p, double *d_sum, hipStre
           // few rays left: one launch follows their trees to the end (or as far as its budget goes)
           {
             ProfScope ps(c, prof, MIPT_K_TAIL, n, st);
-            launch_tail(c->dev, rc, q[cur], n, q[cur ^ 1], bc, accum, st);
+            launch_tail(c->dev, rc, q[cur], n, q[cur ^ 1], nullptr, 0, bc, accum, st);
           }
           HIP_TRY(c, hipGetLastError());
           BatchCounts ht;
@@ -722,10 +729,6 @@ static int render_core(mipt_ctx *c, const mipt_params *p, double *d_sum, hipStre
           cur ^= 1;
           continue;
         }
-        {
-          ProfScope ps(c, prof, MIPT_K_INTERSECT, n, st);
-          launch_intersect(c->dev, rc, q[cur], n, dup, hit_t, hit_prim, dc, count, st);
-        }
         // where this level's shaded hits go: the whole list, or (two streams, few enough rays) one half of it
         // (wide levels fill the chip by themselves and only lose by sharing it: they stay on one stream)
         const bool halves = overlap && n <= half && n <= c->overlap_rays;
@@ -734,12 +737,26 @@ static int render_core(mipt_ctx *c, const mipt_params *p, double *d_sum, hipStre
         const uint32_t sl_off = halves && side ? half : 0u;
         RenderConst rc_l = rc;
         if (halves) rc_l.shade_capacity = half;
+        ShadeList sl_l = offset_shade(sl, sl_off);
+        // Few rays left in a mesh scene: one launch follows their trees to the end, closest hits and shading only,
+        // and hands its shaded hits over as one level's worth would be; the shadow kernels then run once for all of
+        // them.  Its waves work `fuse_budget` rounds at most, which bounds what they can append to the list.
+        uint32_t fuse_budget = 0;
+        if (halves && dup == 1 && spilled == 0 && n <= c->fuse_rays && (uint64_t)5 * n + 2048 <= cap)
+          fuse_budget = (uint32_t)std::min<uint64_t>(4096, rc_l.shade_capacity / ((uint64_t)tail_grid(rc, n) * 256u));
+        const bool fused = fuse_budget >= 48;
+        if (!fused) {
+          ProfScope ps(c, prof, MIPT_K_INTERSECT, n, st);
+          launch_intersect(c->dev, rc, q[cur], n, dup, hit_t, hit_prim, dc, count, st);
+        }
         if (overlap) {
           for (int k = 0; k < 2; k++)
             if (reading[k] && (!halves || k == side)) HIP_TRY(c, hipStreamWaitEvent(st, c->summed[k], 0));
         }
-        ShadeList sl_l = offset_shade(sl, sl_off);
-        {
+        if (fused) {
+          ProfScope ps(c, prof, MIPT_K_TAIL, n, st);
+          launch_tail(c->dev, rc_l, q[cur], n, q[cur ^ 1], &sl_l, fuse_budget, bc, accum, st);
+        } else {
           ProfScope ps(c, prof, MIPT_K_SHADE, n, st);
           launch_shade(c->dev, rc_l, q[cur], n, dup, hit_t, hit_prim, q[cur ^ 1], sl_l, bc, accum, dc, count, st);
           dup = 1;

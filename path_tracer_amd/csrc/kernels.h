@@ -67,7 +67,12 @@ void launch_shade(const SceneDev &S, const RenderConst &rc, RayQueue q, uint32_t
                   DeviceCounters *dc, bool count, hipStream_t st);
 // Finishes the path trees of the `n` rays of `q` depth first, wave by wave; rays it does not get to (a wave's
 // budget of rounds, a full wave stack) are appended to `next` and counted in bc->next_rays.
-void launch_tail(const SceneDev &S, const RenderConst &rc, RayQueue q, uint32_t n, RayQueue next, BatchCounts *bc, double *accum, hipStream_t st);
+// sl == null: the launch traces the shadow rays of its shaded hits itself.  Else it appends the hits to *sl
+// (bc->shades counts them) for the shadow kernels, every wave working at most `budget` rounds: the caller
+// makes sure tail_grid(rc, n) x 4 waves x 64 x budget records fit the list.
+unsigned tail_grid(const RenderConst &rc, uint32_t n);
+void launch_tail(const SceneDev &S, const RenderConst &rc, RayQueue q, uint32_t n, RayQueue next, const ShadeList *sl, uint32_t budget, BatchCounts *bc,
+                 double *accum, hipStream_t st);
 void launch_copy_rays(RayQueue src, uint64_t src_off, RayQueue dst, uint64_t dst_off, uint32_t n, hipStream_t st);
 // vis: scratch for the per-ray shadow results, room for vis_rays rays (1 double each, 3 in
 // translucent scenes); the hits are processed in chunks that fit it.

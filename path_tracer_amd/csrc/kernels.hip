@@ -844,8 +844,13 @@ struct TailWaveStack {
   uint32_t hit_slot[64];
 };
 
-template <bool WALK, bool LOCAL>
-__global__ void __launch_bounds__(kBlock, 2) k_tail(SceneDev S, RenderConst rc, RayQueue q, uint32_t n, RayQueue nq, BatchCounts *bc, double *accum) {
+// EXPORT: the shaded hits are appended to the shade list `sl` (counted in bc->shades) instead of
+// having their shadow rays traced here; the host then runs the shadow kernels once over all of
+// them.  `budget` bounds the rounds of a wave, and with them what the launch can append:
+// waves x 64 x budget records.
+template <bool WALK, bool LOCAL, bool EXPORT>
+__global__ void __launch_bounds__(kBlock, 2) k_tail(SceneDev S, RenderConst rc, RayQueue q, uint32_t n, RayQueue nq, ShadeList sl, uint32_t budget,
+                                                     BatchCounts *bc, double *accum) {
   extern __shared__ uint32_t lds_stack[];
   __shared__ TailWaveStack pend_all[kBlock / 64];
   const Stack stack{lds_stack + threadIdx.x, kBlock, blockIdx.x * kBlock + threadIdx.x};
@@ -978,7 +983,28 @@ __global__ void __launch_bounds__(kBlock, 2) k_tail(SceneDev S, RenderConst rc, 
     // ---- the direct diffuse term (material.cpp:111-130): the shadow rays of the round's shaded hits,
     // dealt out over all 64 lanes (a wave that is down to a few long paths would otherwise trace each
     // hit's rays one after the other on one lane) ----
-    {
+    if (EXPORT) {
+      const bool shade = active && r.emitShade;
+      const unsigned long long sm = __ballot(shade);
+      if (sm != 0ull) {
+        const uint32_t first = (uint32_t)__ffsll((long long)sm) - 1u;
+        uint32_t base = 0;
+        if (lane == first) base = atomicAdd(&bc->shades, (uint32_t)__popcll(sm));
+        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)__shfl((int)base, (int)first));
+        if (shade) {
+          const uint32_t i = base + rank_below(sm, lane);
+          if (i < rc.shade_capacity) {
+            sl.px[i] = r.P.x; sl.py[i] = r.P.y; sl.pz[i] = r.P.z;
+            sl.nx[i] = r.N.x; sl.ny[i] = r.N.y; sl.nz[i] = r.N.z;
+            sl.wx[i] = r.W.x; sl.wy[i] = r.W.y; sl.wz[i] = r.W.z;
+            sl.key[i] = key;
+            sl.slot[i] = slot;
+          } else {
+            bc->overflow = 1;
+          }
+        }
+      }
+    } else {
       const bool shade = active && r.emitShade;
       const unsigned long long sm = __ballot(shade);
       const uint32_t n_shade = (uint32_t)__popcll(sm);
@@ -1022,7 +1048,7 @@ __global__ void __launch_bounds__(kBlock, 2) k_tail(SceneDev S, RenderConst rc, 
       depth = depth + 1;
     }
     active = bounce;
-    if (round + 1 >= kTailBudget) stop = true;
+    if ((uint32_t)round + 1u >= budget) stop = true;
     if (stop) {  // the lanes' own rays go back too
       emit_out(active, o, d, T, key, slot, depth);
       active = false;
@@ -1236,11 +1262,23 @@ void launch_shadow_sum(const SceneDev &S, ShadeList sl, uint64_t first_hit, uint
 }
 
 // Grid of the tail kernel: one lane per input ray, at most the two blocks per CU it is compiled for.
-void launch_tail(const SceneDev &S, const RenderConst &rc, RayQueue q, uint32_t n, RayQueue next, BatchCounts *bc, double *accum, hipStream_t st) {
+// sl == null: the shadow rays of the shaded hits are traced inside the launch; else the hits are
+// appended to *sl (the caller has checked that waves x 64 x budget records fit it).
+void launch_tail(const SceneDev &S, const RenderConst &rc, RayQueue q, uint32_t n, RayQueue next, const ShadeList *sl, uint32_t budget, BatchCounts *bc,
+                 double *accum, hipStream_t st) {
   if (!n) return;
-  uint64_t full = (n + kBlock - 1) / kBlock, cap = (uint64_t)rc.persist_blocks;  // persist_blocks >= CUs, within the stack overflow area
-  auto kern = S.local_meshes ? (S.translucent ? k_tail<true, true> : k_tail<false, true>) : (S.translucent ? k_tail<true, false> : k_tail<false, false>);
-  hipLaunchKernelGGL(kern, dim3((unsigned)(full < cap ? full : cap)), dim3(kBlock), stack_bytes(S), st, S, rc, q, n, next, bc, accum);
+  const unsigned grid = tail_grid(rc, n);
+  if (sl) {
+    auto kern = S.local_meshes ? k_tail<false, true, true> : k_tail<false, false, true>;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), stack_bytes(S), st, S, rc, q, n, next, *sl, budget, bc, accum);
+    return;
+  }
+  auto kern = S.local_meshes ? (S.translucent ? k_tail<true, true, false> : k_tail<false, true, false>) : (S.translucent ? k_tail<true, false, false> : k_tail<false, false, false>);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), stack_bytes(S), st, S, rc, q, n, next, ShadeList{}, (uint32_t)kTailBudget, bc, accum);
+}
+unsigned tail_grid(const RenderConst &rc, uint32_t n) {
+  uint64_t full = ((uint64_t)n + kBlock - 1) / kBlock, cap = (uint64_t)rc.persist_blocks;  // persist_blocks >= CUs, within the stack overflow area
+  return (unsigned)(full < cap ? full : cap);
 }
 
 void launch_resolve(const RenderConst &rc, const double *accum, const int *rows, int64_t first_pixel, int n_pixels, int n_samples,
