@@ -432,9 +432,11 @@ def test_two_launch_streams_give_the_one_stream_frame(scenes, monkeypatch):
     # the order of the atomic adds into a sample's accumulator.
     from path_tracer_amd.raytracer import Context
     frames = {}
-    for knob, rays in (("0", "0"), ("1", "1073741824"), ("1", "4096")):   # one stream; every level that fits a half list; narrow levels only
+    # one stream; every level that fits a half list on two; narrow levels only; the same without the fused tail launch of mesh scenes
+    for knob, rays, fuse in (("0", "0", "0"), ("1", "1073741824", "1048576"), ("1", "4096", "4096"), ("1", "4096", "0")):
         monkeypatch.setenv("MIPT_OVERLAP", knob)
         monkeypatch.setenv("MIPT_OVERLAP_RAYS", rays)
+        monkeypatch.setenv("MIPT_FUSE_RAYS", fuse)
         ctx = Context(0)
         try:
             for name in ("cornellBoxes", "areaLight", "mesh"):
@@ -444,9 +446,10 @@ def test_two_launch_streams_give_the_one_stream_frame(scenes, monkeypatch):
                     frames.setdefault((name, batch), []).append(ctx.render(p, want_rgb8=False)[0].astype(np.float64))
         finally:
             ctx.close()
-    for key, (one, every, narrow) in frames.items():
+    for key, (one, *others) in frames.items():
         assert one.max() > 0.05, key
-        assert np.abs(every - one).max() <= 1e-6 and np.abs(narrow - one).max() <= 1e-6, key  # float32 frames: an ulp at most
+        for other in others:
+            assert np.abs(other - one).max() <= 1e-6, key  # float32 frames: an ulp at most
 
 
 # ------------------------------------------------------------------ edge cases
