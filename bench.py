@@ -367,16 +367,19 @@ def scene_rays_per_hit(scene, area_samples):
     return sum(area_samples if L.type == abi.LIGHT_RECT_AREA else 1 for L in scene.lights)
 
 
-def load_counters(workload, kernel):
+def load_counters(workload, kernel, step_samples=None):
     """The rocprofv3 counter summary of `kernel` on `workload` (profiles/counters.json, written by
     tools/make_counters.py from separate --pmc passes over one bench step), or None when there is
-    none or when it was measured on other kernel sources than the ones this run uses."""
+    none, when it was measured on other kernel sources than the ones this run uses, or (step_samples
+    given) on a step of another size: its figures are per launch, and a launch is as large as the step."""
     try:
         with open(os.path.join(ROOT, "profiles", "counters.json")) as fh:
             entry = json.load(fh).get(workload)
     except (OSError, ValueError):
         return None
     if not entry or entry.get("kernel_source_hash") != kernel_source_hash():
+        return None
+    if step_samples is not None and entry.get("step_samples") != step_samples:
         return None
     return entry.get("kernels", {}).get(kernel)
 
@@ -391,8 +394,8 @@ def roofline(workload, scene_bytes, ktimes, K, cnt, step_samples):
     scene still finds 57 % of its reads in L2), so it is the issue roof, with the vector-L1 path
     (`tcp_busy`) saturating beside it.  Launch durations are this run's own (HIP events on
     the launch stream around every launch of the timed steps); instruction counts and HBM-side
-    bytes per launch come from the committed counter passes of the same kernel sources, and are
-    null when the sources have changed since.  The algorithmic-byte rate is always reported as
+    bytes per launch come from the committed counter passes of the same kernel sources over a step of
+    the same size, and are null otherwise.  The algorithmic-byte rate is always reported as
     `cache_served_gbs`; it is a roofline fraction only where HBM is the bound."""
     dominant = max(("intersect", "shadow"), key=lambda k: ktimes[k]["ms"])
     name = "k_shadow_any" if dominant == "shadow" else "k_intersect"
@@ -403,7 +406,9 @@ def roofline(workload, scene_bytes, ktimes, K, cnt, step_samples):
     avg_launch_s = kt["ms"] / kt["launches"] * 1e-3
     alg_bytes_launch = algorithmic_bytes(cnt, dominant) / max(1.0, launches_step)
     cache_served = alg_bytes_launch / avg_launch_s / 1e9
-    pmc = load_counters(workload, name)
+    pmc = load_counters(workload, name, step_samples)
+    if pmc and abs(pmc.get("launches_per_step", launches_step) - launches_step) > 0.05 * launches_step:
+        pmc = None  # another launch sequence than the one the passes averaged over
     traffic = pmc.get("hbm_bytes_per_launch") if pmc else None
     r = {
         "kernel": name,

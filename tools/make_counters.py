@@ -17,7 +17,9 @@ Per timed kernel (the non-counting instantiations of k_intersect / k_shadow_any 
   ta_busy, tcp_busy  TA_TA_BUSY_sum, TCP_GATE_EN1_sum / (256 CUs x kernel cycles)
   l1_miss_rate     TCP_TCC_READ_REQ_sum / TCP_TOTAL_CACHE_ACCESSES_sum
   l2_hit_rate      TCC_HIT_sum / (TCC_HIT_sum + TCC_MISS_sum)
-The entry carries the hash of the kernel sources it was measured on (path_tracer_amd/buildinfo.py).
+The entry carries the hash of the kernel sources it was measured on (path_tracer_amd/buildinfo.py) and
+the size of the step the passes ran (step_samples, launches_per_step): bench.py quotes it only for a run
+of the same sources and the same step.
 """
 import csv, glob, json, os, re, sys
 from collections import defaultdict
@@ -42,7 +44,8 @@ def kernel_of(name):
 
 def read_pass(d):
     out, calls = defaultdict(lambda: defaultdict(float)), defaultdict(lambda: defaultdict(set))
-    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+    files = sorted(glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True), key=os.path.getmtime)
+    for f in files[-1:]:  # one run per pass: a directory that was used before also holds the older runs' files
         with open(f) as fh:
             for row in csv.DictReader(fh):
                 k = kernel_of(row["Kernel_Name"])
@@ -107,13 +110,19 @@ def main():
             e["tcp_busy"] = val("TCP_GATE_EN1_sum") / (CUS * cyc("m1", "TCP_GATE_EN1_sum"))
         if "TCP_TCC_READ_REQ_sum" in c and val("TCP_TOTAL_CACHE_ACCESSES_sum"):
             e["l1_miss_rate"] = val("TCP_TCC_READ_REQ_sum") / val("TCP_TOTAL_CACHE_ACCESSES_sum")
+        lps = per_step["sq1"].get(KEY.get(k, ""))
+        if lps:
+            e["launches_per_step"] = lps  # per-launch figures are averages over the launches of such a step
         kernels[k] = e
+    step = bench_json(os.path.join(d, "sq1.json")) or {}
     out = {}
     if dest and os.path.exists(dest):
         out = json.load(open(dest))
     out[workload] = {
         "kernel_source_hash": kernel_source_hash(),
         "measured": tag,
+        # the step the passes ran: per-launch averages hold for steps of this size only
+        "step_samples": (step.get("counters") or {}).get("samples"),
         "clock_hz_assumed": CLOCK,
         "note": "one bench step per pass under rocprofv3 --pmc (separate passes; kernels run a few % slower than untraced)",
         "kernels": kernels,
