@@ -702,7 +702,10 @@ static int render_core(mipt_ctx *c, const mipt_params *p, double *d_sum, hipStre
       int ns = std::min(SB, p->sample_end - s0);
       uint32_t n = (uint32_t)((int64_t)npix * ns);
       HIP_TRY(c, hipMemsetAsync(accum, 0, (size_t)n * 3 * sizeof(double), st));
-      {
+      // a batch of several samples per pixel never stores its camera rays: the level that traces and shades
+      // them computes them from their index
+      const CameraRays cam{d_rows, p0, npix, s0, ns};
+      if (ns == 1) {
         ProfScope ps(c, prof, MIPT_K_GENERATE, n, st);
         launch_generate(c->dev, rc, d_rows, p0, npix, s0, ns, q[0], st);
       }
@@ -747,7 +750,7 @@ static int render_core(mipt_ctx *c, const mipt_params *p, double *d_sum, hipStre
         const bool fused = fuse_budget >= 48;
         if (!fused) {
           ProfScope ps(c, prof, MIPT_K_INTERSECT, n, st);
-          launch_intersect(c->dev, rc, q[cur], n, dup, hit_t, hit_prim, dc, count, st);
+          launch_intersect(c->dev, rc, q[cur], n, dup, hit_t, hit_prim, dc, count, dup > 1 ? &cam : nullptr, st);
         }
         if (overlap) {
           for (int k = 0; k < 2; k++)
@@ -758,7 +761,7 @@ static int render_core(mipt_ctx *c, const mipt_params *p, double *d_sum, hipStre
           launch_tail(c->dev, rc_l, q[cur], n, q[cur ^ 1], &sl_l, fuse_budget, bc, accum, st);
         } else {
           ProfScope ps(c, prof, MIPT_K_SHADE, n, st);
-          launch_shade(c->dev, rc_l, q[cur], n, dup, hit_t, hit_prim, q[cur ^ 1], sl_l, bc, accum, dc, count, st);
+          launch_shade(c->dev, rc_l, q[cur], n, dup, hit_t, hit_prim, q[cur ^ 1], sl_l, bc, accum, dc, count, dup > 1 ? &cam : nullptr, st);
           dup = 1;
         }
         HIP_TRY(c, hipGetLastError());  // a launch that failed must not read as "the tree ended here"

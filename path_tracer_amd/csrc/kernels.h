@@ -56,15 +56,23 @@ struct RenderConst {
   int persist_blocks; // grid of the persistent traversal kernels (CUs x resident blocks per CU)
 };
 
+// The camera rays of a batch: entry idx is sample sample0 + idx % n_samples of owned pixel first_pixel + idx / n_samples.
+struct CameraRays {
+  const int *rows;  // frame rows the call owns, bottom-up (device)
+  int64_t first_pixel;
+  int n_pixels, sample0, n_samples;
+};
 void launch_generate(const SceneDev &S, const RenderConst &rc, const int *rows, int64_t first_pixel, int n_pixels,
                      int sample0, int n_samples, RayQueue q, hipStream_t st);
 // dup > 1: the queue holds runs of `dup` identical rays; one ray per run is traced and the
 // whole run is shaded with its result (n must be a multiple of dup, else dup is ignored).
+// cam != null (the level of the camera rays): the rays are computed from their index as k_generate would
+// write them, and `q` is not read: a batch of several samples per pixel never stores its camera rays.
 void launch_intersect(const SceneDev &S, const RenderConst &rc, RayQueue q, uint32_t n, uint32_t dup, double *hit_t, int *hit_prim,
-                      DeviceCounters *dc, bool count, hipStream_t st);
+                      DeviceCounters *dc, bool count, const CameraRays *cam, hipStream_t st);
 void launch_shade(const SceneDev &S, const RenderConst &rc, RayQueue q, uint32_t n, uint32_t dup, const double *hit_t,
                   const int *hit_prim, RayQueue next, ShadeList sl, BatchCounts *bc, double *accum,
-                  DeviceCounters *dc, bool count, hipStream_t st);
+                  DeviceCounters *dc, bool count, const CameraRays *cam, hipStream_t st);
 // Finishes the path trees of the `n` rays of `q` depth first, wave by wave; rays it does not get to (a wave's
 // budget of rounds, a full wave stack) are appended to `next` and counted in bc->next_rays.
 // sl == null: the launch traces the shadow rays of its shaded hits itself.  Else it appends the hits to *sl

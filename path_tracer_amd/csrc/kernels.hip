@@ -143,24 +143,39 @@ __device__ __forceinline__ d3 cube_color(const SceneDev &S, d3 dirIn) {
 }
 
 // ---------------------------------------------------------------- generate ----
-__global__ void __launch_bounds__(kBlock) k_generate(SceneDev S, RenderConst rc, const int *__restrict__ rows, int64_t first_pixel,
-                                                      int n_pixels, int sample0, int n_samples, RayQueue q) {
-  uint32_t idx = blockIdx.x * kBlock + threadIdx.x;
-  uint32_t total = (uint32_t)n_pixels * (uint32_t)n_samples;
-  if (idx >= total) return;
-  uint32_t lp = idx / (uint32_t)n_samples;
-  uint32_t k = idx - lp * (uint32_t)n_samples;
-  int64_t op = first_pixel + lp;
-  int j = rows[op / rc.width];
+// Camera ray `idx` of a batch: direction and the random-stream key of its sample.  (Origin = the eye,
+// throughput 1, accumulator slot idx, depth 0.)
+__device__ __forceinline__ void camera_ray(const SceneDev &S, const RenderConst &rc, const CameraRays &g, uint32_t idx, d3 &dir, uint64_t &key) {
+  uint32_t lp = idx / (uint32_t)g.n_samples;
+  uint32_t k = idx - lp * (uint32_t)g.n_samples;
+  int64_t op = g.first_pixel + lp;
+  int j = g.rows[op / rc.width];
   int i = (int)(op % rc.width);
-  // tracePixel: x = i/w, y = j/h (RayTracer.cpp:70-71); rayThrough (camera.cpp:20-29)
-  double x = (double)i / (double)rc.width - 0.5;
-  double y = (double)j / (double)rc.height - 0.5;
-  d3 dir = normalize((ld3(S.camera.look) + x * ld3(S.camera.u)) + y * ld3(S.camera.v));
+  // tracePixel: x = i/w, y = j/h (RayTracer.cpp:70-71); rayThrough (camera.cpp:20-29):
+  // normalize((look + x u) + y v).  Every operation is rounded by itself (no fused multiply-adds): the
+  // kernel that traces a camera ray and the kernel that shades it compute the same bits, whatever the
+  // compiler would contract in either, and they are the bits the expression has on a CPU.
+  const double x = __dadd_rn((double)i / (double)rc.width, -0.5);
+  const double y = __dadd_rn((double)j / (double)rc.height, -0.5);
+  const double ax = __dadd_rn(__dadd_rn(S.camera.look[0], __dmul_rn(x, S.camera.u[0])), __dmul_rn(y, S.camera.v[0]));
+  const double ay = __dadd_rn(__dadd_rn(S.camera.look[1], __dmul_rn(x, S.camera.u[1])), __dmul_rn(y, S.camera.v[1]));
+  const double az = __dadd_rn(__dadd_rn(S.camera.look[2], __dmul_rn(x, S.camera.u[2])), __dmul_rn(y, S.camera.v[2]));
+  const double inv = 1.0 / sqrt(__dadd_rn(__dadd_rn(__dmul_rn(ax, ax), __dmul_rn(ay, ay)), __dmul_rn(az, az)));
+  dir = d3{__dmul_rn(ax, inv), __dmul_rn(ay, inv), __dmul_rn(az, inv)};
+  key = sample_key(rc.seed, (uint64_t)i + (uint64_t)j * (uint64_t)rc.width, (uint64_t)(g.sample0 + (int)k));
+}
+
+__global__ void __launch_bounds__(kBlock) k_generate(SceneDev S, RenderConst rc, CameraRays g, RayQueue q) {
+  uint32_t idx = blockIdx.x * kBlock + threadIdx.x;
+  uint32_t total = (uint32_t)g.n_pixels * (uint32_t)g.n_samples;
+  if (idx >= total) return;
+  d3 dir;
+  uint64_t key;
+  camera_ray(S, rc, g, idx, dir, key);
   q.ox[idx] = S.camera.eye[0]; q.oy[idx] = S.camera.eye[1]; q.oz[idx] = S.camera.eye[2];
   q.dx[idx] = dir.x; q.dy[idx] = dir.y; q.dz[idx] = dir.z;
   q.tx[idx] = 1.0; q.ty[idx] = 1.0; q.tz[idx] = 1.0;
-  q.key[idx] = sample_key(rc.seed, (uint64_t)i + (uint64_t)j * (uint64_t)rc.width, (uint64_t)(sample0 + (int)k));
+  q.key[idx] = key;
   q.slot[idx] = idx;
   q.depth[idx] = 0;
 }
@@ -282,9 +297,11 @@ __device__ __forceinline__ uint32_t rank_below(unsigned long long mask, uint32_t
 // `dup` > 1: the queue holds runs of `dup` identical rays (the camera rays of one pixel's
 // samples, RayTracer.cpp:72-75 calls trace(x, y) N times with the same x, y); only the first
 // ray of every run is traced, k_shade reads its result for the whole run.  n = rays to trace.
-template <bool COUNT, bool LOCAL>
+// CAM: the level of the camera rays, computed from their index (`cam`) instead of read from `q`.
+template <bool COUNT, bool LOCAL, bool CAM>
 __global__ void __launch_bounds__(kBlock, MIPT_TRAV_WAVES) k_intersect(SceneDev S, RenderConst rc, RayQueue q, uint32_t n, uint32_t dup,
-                                                                        double *__restrict__ hit_t, int *__restrict__ hit_prim, DeviceCounters *dc) {
+                                                                        double *__restrict__ hit_t, int *__restrict__ hit_prim, DeviceCounters *dc,
+                                                                        CameraRays cam) {
   extern __shared__ uint32_t lds_stack[];
   const Stack stack{lds_stack + threadIdx.x, kBlock, blockIdx.x * kBlock + threadIdx.x};
   const uint32_t lane = lane_id();
@@ -309,8 +326,15 @@ __global__ void __launch_bounds__(kBlock, MIPT_TRAV_WAVES) k_intersect(SceneDev 
         uint64_t item = feed_item(take, rnk);
         if (item < n) {
           ray = (uint32_t)item * dup;
-          d3 o{q.ox[ray], q.oy[ray], q.oz[ray]};
-          d3 d{q.dx[ray], q.dy[ray], q.dz[ray]};
+          d3 o, d;
+          if (CAM) {
+            uint64_t key_unused;
+            o = ld3(S.camera.eye);
+            camera_ray(S, rc, cam, ray, d, key_unused);
+          } else {
+            o = d3{q.ox[ray], q.oy[ray], q.oz[ray]};
+            d = d3{q.dx[ray], q.dy[ray], q.dz[ray]};
+          }
           trav_init(T, S, o, d, rc.t_max);
           idle = false;
         }
@@ -449,10 +473,10 @@ __device__ __forceinline__ void path_node(const SceneDev &S, const RenderConst &
   r.wdir = wdir;
 }
 
-template <bool COUNT>
+template <bool COUNT, bool CAM>
 __global__ void __launch_bounds__(kShadeBlock) k_shade(SceneDev S, RenderConst rc, RayQueue q, uint32_t n, uint32_t dup, const double *__restrict__ hit_t,
                                                    const int *__restrict__ hit_prim, RayQueue nq, ShadeList sl, BatchCounts *bc,
-                                                   double *accum, DeviceCounters *dc) {
+                                                   double *accum, DeviceCounters *dc, CameraRays cam) {
   uint32_t idx = blockIdx.x * kShadeBlock + threadIdx.x;
   bool live = idx < n;
   NodeOut r;
@@ -463,12 +487,21 @@ __global__ void __launch_bounds__(kShadeBlock) k_shade(SceneDev S, RenderConst r
   if (live) {
     const uint32_t hidx = dup > 1u ? idx - idx % dup : idx;  // the run's traced ray
     int prim = hit_prim[hidx];
-    d3 o{q.ox[idx], q.oy[idx], q.oz[idx]};
-    d3 d{q.dx[idx], q.dy[idx], q.dz[idx]};
-    d3 T{q.tx[idx], q.ty[idx], q.tz[idx]};
-    key = q.key[idx];
-    slot = q.slot[idx];
-    depth = (int)q.depth[idx];
+    d3 o, d, T;
+    if (CAM) {
+      o = ld3(S.camera.eye);
+      camera_ray(S, rc, cam, idx, d, key);
+      T = d3{1.0, 1.0, 1.0};
+      slot = idx;
+      depth = 0;
+    } else {
+      o = d3{q.ox[idx], q.oy[idx], q.oz[idx]};
+      d = d3{q.dx[idx], q.dy[idx], q.dz[idx]};
+      T = d3{q.tx[idx], q.ty[idx], q.tz[idx]};
+      key = q.key[idx];
+      slot = q.slot[idx];
+      depth = (int)q.depth[idx];
+    }
     path_node(S, rc, o, d, T, key, slot, depth, prim, prim >= 0 ? hit_t[hidx] : 0.0, accum, r);
   }
   const bool emitBounce = r.emitBounce, emitMirror = r.emitMirror, emitShade = r.emitShade, shaded = r.shaded;
@@ -1183,7 +1216,7 @@ void launch_generate(const SceneDev &S, const RenderConst &rc, const int *rows, 
                      int n_samples, RayQueue q, hipStream_t st) {
   uint64_t total = (uint64_t)n_pixels * (uint64_t)n_samples;
   if (!total) return;
-  hipLaunchKernelGGL(k_generate, dim3(grid_for(total)), dim3(kBlock), 0, st, S, rc, rows, first_pixel, n_pixels, sample0, n_samples, q);
+  hipLaunchKernelGGL(k_generate, dim3(grid_for(total)), dim3(kBlock), 0, st, S, rc, CameraRays{rows, first_pixel, n_pixels, sample0, n_samples}, q);
 }
 
 // Grid of a persistent traversal kernel: enough blocks to fill every CU at the compiled
@@ -1195,21 +1228,27 @@ static inline unsigned persistent_grid(const RenderConst &rc, uint64_t n) {
 }
 
 void launch_intersect(const SceneDev &S, const RenderConst &rc, RayQueue q, uint32_t n, uint32_t dup, double *hit_t, int *hit_prim,
-                      DeviceCounters *dc, bool count, hipStream_t st) {
+                      DeviceCounters *dc, bool count, const CameraRays *cam, hipStream_t st) {
   if (!n) return;
   if (dup < 1u || n % dup != 0u) dup = 1u;
   uint32_t traced = n / dup;
-  auto kern = S.local_meshes ? (count ? k_intersect<true, true> : k_intersect<false, true>) : (count ? k_intersect<true, false> : k_intersect<false, false>);
+  auto kern = S.local_meshes ? (count ? k_intersect<true, true, false> : k_intersect<false, true, false>)
+                             : (count ? k_intersect<true, false, false> : k_intersect<false, false, false>);
+  if (cam)
+    kern = S.local_meshes ? (count ? k_intersect<true, true, true> : k_intersect<false, true, true>)
+                          : (count ? k_intersect<true, false, true> : k_intersect<false, false, true>);
   (void)hipMemsetAsync(dc->dyn_next, 0, sizeof(dc->dyn_next), st);
-  hipLaunchKernelGGL(kern, dim3(persistent_grid(rc, traced)), dim3(kBlock), stack_bytes(S), st, S, rc, q, traced, dup, hit_t, hit_prim, dc);
+  hipLaunchKernelGGL(kern, dim3(persistent_grid(rc, traced)), dim3(kBlock), stack_bytes(S), st, S, rc, q, traced, dup, hit_t, hit_prim, dc,
+                     cam ? *cam : CameraRays{nullptr, 0, 0, 0, 1});
 }
 
 void launch_shade(const SceneDev &S, const RenderConst &rc, RayQueue q, uint32_t n, uint32_t dup, const double *hit_t, const int *hit_prim,
-                  RayQueue next, ShadeList sl, BatchCounts *bc, double *accum, DeviceCounters *dc, bool count, hipStream_t st) {
+                  RayQueue next, ShadeList sl, BatchCounts *bc, double *accum, DeviceCounters *dc, bool count, const CameraRays *cam, hipStream_t st) {
   if (!n) return;
   if (dup < 1u || n % dup != 0u) dup = 1u;
-  auto kern = count ? k_shade<true> : k_shade<false>;
-  hipLaunchKernelGGL(kern, dim3((n + kShadeBlock - 1) / kShadeBlock), dim3(kShadeBlock), 0, st, S, rc, q, n, dup, hit_t, hit_prim, next, sl, bc, accum, dc);
+  auto kern = cam ? (count ? k_shade<true, true> : k_shade<false, true>) : (count ? k_shade<true, false> : k_shade<false, false>);
+  hipLaunchKernelGGL(kern, dim3((n + kShadeBlock - 1) / kShadeBlock), dim3(kShadeBlock), 0, st, S, rc, q, n, dup, hit_t, hit_prim, next, sl, bc, accum, dc,
+                     cam ? *cam : CameraRays{nullptr, 0, 0, 0, 1});
 }
 
 // Moves `n` ray records between queues (spill to / refill from the overflow stack).
