@@ -178,9 +178,12 @@ __device__ __forceinline__ bool tri_hit(const Tri *tr, d3 org, d3 dir, double &t
 
 // ---- conservative fp32 slab culling --------------------------------------------
 // A plane at coordinate b is crossed at t = b * id + off, with off lowered (near planes)
-// or raised (far planes) by pad = 2^-21 * (R + |o|) * |1/d|: more than the error of
+// or raised (far planes) by pad = 1.25 * 2^-21 * (R + |o|) * |1/d|: more than the error of
 // rounding the origin and the reciprocal to fp32 and of evaluating b * id in two fmas
-// (node_test).  Axis-parallel rays use |d| = 1e-30.
+// (node_test), 2^-21 of it, plus the rounding of off itself to fp32 (to nearest: |off| <=
+// (R + |o|) |1/d| (1 + 2^-20), so it moves by less than the 2^-23 share; a conversion with
+// directed rounding is twelve instructions on this chip, to nearest it is one).
+// Axis-parallel rays use |d| = 1e-30.
 struct Cull {
   float idx, idy, idz;
   float nx, ny, nz;  // near-plane offsets
@@ -189,15 +192,14 @@ struct Cull {
 
 __device__ __forceinline__ void cull_axis(double o, double d, double R, float &id, float &offN, float &offF) {
   double dd = fabs(d) < 1e-30 ? copysign(1e-30, d) : d;
-  // 1/dd to ~1e-15 (hardware estimate + two Newton steps): it only feeds the fp32 culling
+  // 1/dd to ~1e-15 (the hardware estimate is good to 2^-26, one Newton step squares that): it only feeds the fp32 culling
   double inv = __builtin_amdgcn_rcp(dd);
   inv = fma(fma(-dd, inv, 1.0), inv, inv);
-  inv = fma(fma(-dd, inv, 1.0), inv, inv);
   double oi = o * inv;
-  double pad = 4.76837158203125e-07 * (R + fabs(o)) * fabs(inv);
+  double pad = 5.9604644775390625e-07 * (R + fabs(o)) * fabs(inv);
   id = (float)inv;
-  offN = __double2float_rd(-(oi + pad));
-  offF = __double2float_ru(-(oi - pad));
+  offN = (float)(-(oi + pad));
+  offF = (float)(-(oi - pad));
 }
 
 __device__ __forceinline__ Cull make_cull(d3 o, d3 d, double R) {
@@ -259,7 +261,7 @@ __device__ __forceinline__ void trav_init(Trav &T, const SceneDev &S, d3 org, d3
   T.org = org;
   T.dir = dir;
   T.c = make_cull(org, dir, S.radius);
-  T.tlimit = __double2float_ru(tmax) * 1.0000005f;
+  T.tlimit = (float)tmax * 1.000001f;  // >= tmax: to nearest loses 2^-24, the factor adds 2^-20
   T.cur = 0;  // the root is always an inner node
   T.sp = 0;
   T.best.t = tmax;
@@ -287,7 +289,7 @@ __device__ __forceinline__ float ubyte_f(uint32_t w, int k) { return (float)((w 
 // The ray is moved into the node's quantised frame once (per axis
 // t = q * (step / d) + ((origin - o) / d -+ pad)), then each child costs six byte->float
 // conversions and six fmas.  The errors stay inside the pad of make_cull: in units of
-// 2^-24 (R + |o|) |1/d|, of which the pad holds 8, the rounded reciprocal costs one and each
+// 2^-24 (R + |o|) |1/d|, of which the pad holds 10 (2 of them for its own rounding), the rounded reciprocal costs one and each
 // of the two chained fmas one (|t| of a plane never exceeds (R + |o|) |1/d| by more than the
 // 1 % the quantised root box may stick out), so near and far values can be compared as they are.
 template <bool NEED_T>
@@ -345,7 +347,7 @@ __device__ __forceinline__ bool prim_test(Trav &T, const SceneDev &S, uint32_t s
   if (!closer) return false;
   T.best.t = t;
   T.best.prim = (int)s;
-  T.tlimit = __double2float_ru(t) * 1.0000005f;
+  T.tlimit = (float)t * 1.000001f;
   return true;
 }
 
