@@ -148,9 +148,10 @@ __device__ __forceinline__ d3 cube_color(const SceneDev &S, d3 dirIn) {
 __device__ __forceinline__ void camera_ray(const SceneDev &S, const RenderConst &rc, const CameraRays &g, uint32_t idx, d3 &dir, uint64_t &key) {
   uint32_t lp = idx / (uint32_t)g.n_samples;
   uint32_t k = idx - lp * (uint32_t)g.n_samples;
-  int64_t op = g.first_pixel + lp;
-  int j = g.rows[op / rc.width];
-  int i = (int)(op % rc.width);
+  const uint32_t op = (uint32_t)g.first_pixel + lp;  // owned pixels are fewer than 2^30 (the frame is): 32-bit divisions
+  const uint32_t row = op / (uint32_t)rc.width;
+  int j = g.rows[row];
+  int i = (int)(op - row * (uint32_t)rc.width);
   // tracePixel: x = i/w, y = j/h (RayTracer.cpp:70-71); rayThrough (camera.cpp:20-29):
   // normalize((look + x u) + y v).  Every operation is rounded by itself (no fused multiply-adds): the
   // kernel that traces a camera ray and the kernel that shades it compute the same bits, whatever the
