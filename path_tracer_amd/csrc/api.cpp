@@ -41,11 +41,12 @@ constexpr uint32_t kStaticShadeCap = (uint32_t)(kStaticBatch + 1024);
 constexpr int kStaticMaxRows = 16384;                                // frame height limit
 constexpr uint32_t kStaticMaxRaysPerHit = 65536;                     // shadow rays per shaded hit (light table entries)
 constexpr size_t kStaticEntryBytes = 10 * sizeof(double) + sizeof(uint32_t) + 1;  // = kEntryBytes below
+constexpr size_t kStaticShadeEntryBytes = 10 * sizeof(double) + 2 * sizeof(uint32_t);  // = kShadeEntryBytes below
 constexpr size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 constexpr size_t kOffQueue0 = 0;
 constexpr size_t kOffQueue1 = kOffQueue0 + align256((size_t)kStaticCap * kStaticEntryBytes + 64);
 constexpr size_t kOffShade = kOffQueue1 + align256((size_t)kStaticCap * kStaticEntryBytes + 64);
-constexpr size_t kOffHits = kOffShade + align256((size_t)kStaticShadeCap * kStaticEntryBytes + 64);
+constexpr size_t kOffHits = kOffShade + align256((size_t)kStaticShadeCap * kStaticShadeEntryBytes + 64);
 constexpr size_t kOffAccum = kOffHits + align256((size_t)kStaticCap * (sizeof(double) + sizeof(int)) + 64);
 constexpr size_t kOffRows = kOffAccum + align256((size_t)kStaticBatch * 3 * sizeof(double));
 constexpr size_t kOffCounts = kOffRows + align256((size_t)kStaticMaxRows * sizeof(int));
@@ -226,6 +227,7 @@ ShadeList carve_shade(void *base, uint32_t cap) {
   s.wx = d + 6ull * cap; s.wy = d + 7ull * cap; s.wz = d + 8ull * cap;
   s.key = reinterpret_cast<uint64_t *>(d + 9ull * cap);
   s.slot = reinterpret_cast<uint32_t *>(d + 10ull * cap);
+  s.prim = s.slot + cap;
   return s;
 }
 ShadeList offset_shade(ShadeList s, uint32_t first) {  // the list that starts at entry `first` of `s`
@@ -234,10 +236,13 @@ ShadeList offset_shade(ShadeList s, uint32_t first) {  // the list that starts a
   s.wx += first; s.wy += first; s.wz += first;
   s.key += first;
   s.slot += first;
+  s.prim += first;
   return s;
 }
-constexpr size_t kEntryBytes = 10 * sizeof(double) + sizeof(uint32_t) + 1;  // per queue / shade-list entry
+constexpr size_t kEntryBytes = 10 * sizeof(double) + sizeof(uint32_t) + 1;  // per queue entry
+constexpr size_t kShadeEntryBytes = 10 * sizeof(double) + 2 * sizeof(uint32_t);  // per shade-list entry
 static_assert(kEntryBytes == kStaticEntryBytes, "the static workspace is laid out for this entry size");
+static_assert(kShadeEntryBytes == kStaticShadeEntryBytes, "the static workspace is laid out for this entry size");
 
 int check_params(mipt_ctx *c, const mipt_params *p) {
   if (!p) return set_err(c, MIPT_ERR_INVALID, "null params");
@@ -879,7 +884,7 @@ int mipt_render_accumulate(mipt_ctx *c, const mipt_params *p, double *d_sum, voi
   ws.shade_cap = (uint32_t)(batch + 1024);  // the shade list and the visibility buffer are sized by the batch, not by the queues
   if ((r = ensure(c, c->queue[0], (size_t)ws.cap * kEntryBytes + 64)) != MIPT_OK) return r;
   if ((r = ensure(c, c->queue[1], (size_t)ws.cap * kEntryBytes + 64)) != MIPT_OK) return r;
-  if ((r = ensure(c, c->shade, (size_t)ws.shade_cap * kEntryBytes + 64)) != MIPT_OK) return r;
+  if ((r = ensure(c, c->shade, (size_t)ws.shade_cap * kShadeEntryBytes + 64)) != MIPT_OK) return r;
   if ((r = ensure(c, c->hits, (size_t)ws.cap * (sizeof(double) + sizeof(int)) + 64)) != MIPT_OK) return r;
   if ((r = ensure(c, c->accum, (size_t)batch * 3 * sizeof(double))) != MIPT_OK) return r;
   if ((r = ensure(c, c->rows, rows.size() * sizeof(int))) != MIPT_OK) return r;

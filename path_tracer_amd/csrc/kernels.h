@@ -27,6 +27,7 @@ struct ShadeList {
   double *wx, *wy, *wz;  // T * kd / pi * (1 - metallic) / norm
   uint64_t *key;
   uint32_t *slot;
+  uint32_t *prim;        // the primitive the hit lies on (storage index)
 };
 
 struct DeviceCounters {

@@ -195,6 +195,9 @@ __global__ void __launch_bounds__(kBlock) k_generate(SceneDev S, RenderConst rc,
 #ifndef MIPT_REFILL_IDLE_CLOSEST
 #define MIPT_REFILL_IDLE_CLOSEST MIPT_REFILL_IDLE
 #endif
+#ifndef MIPT_OWN_PRIM_FIRST
+#define MIPT_OWN_PRIM_FIRST 1  // any-hit shadow rays that start into their own surface test the primitive they start on first
+#endif
 constexpr uint32_t kRefillIdle = MIPT_REFILL_IDLE;                  // shadow rays
 constexpr uint32_t kRefillIdleClosest = MIPT_REFILL_IDLE_CLOSEST;  // path rays
 
@@ -485,9 +488,10 @@ __global__ void __launch_bounds__(kShadeBlock) k_shade(SceneDev S, RenderConst r
   uint64_t key = 0;
   uint32_t slot = 0;
   int depth = 0;
+  int hprim = -1;
   if (live) {
     const uint32_t hidx = dup > 1u ? idx - idx % dup : idx;  // the run's traced ray
-    int prim = hit_prim[hidx];
+    int prim = hprim = hit_prim[hidx];
     d3 o, d, T;
     if (CAM) {
       o = ld3(S.camera.eye);
@@ -543,6 +547,7 @@ __global__ void __launch_bounds__(kShadeBlock) k_shade(SceneDev S, RenderConst r
       sl.wx[is] = W.x; sl.wy[is] = W.y; sl.wz[is] = W.z;
       sl.key[is] = key;
       sl.slot[is] = slot;
+      sl.prim[is] = (uint32_t)hprim;
     } else {
       bc->overflow = 1;
     }
@@ -697,8 +702,26 @@ __global__ void __launch_bounds__(kBlock, MIPT_TRAV_WAVES) k_shadow_any(SceneDev
           scale = su.scale;
           trav_init(T, S, fire, su.dir, fmin(su.lightT, rc.t_max));
           idle = false;
+#if MIPT_OWN_PRIM_FIRST
+          // A ray that leaves toward the far side of its own surface starts 3e-8 above it and
+          // crosses it at once: the primitive the hit lies on is its occluder.  Testing that
+          // primitive first ends such a ray without a walk; any primitive closer than the light
+          // blocks the ray, so which one is found does not matter.  A ray it does not block
+          // (a hit near an edge, a smooth normal on the other side) walks as usual.
+          if (dot(N, su.dir) < 0.0) {
+            if (COUNT) tc.prims++;
+            if (prim_test<true, LOCAL>(T, S, sl.prim[h])) {
+              vis[item] = 0.0;
+              idle = true;
+            }
+          }
+#endif
         }
       }
+#if MIPT_OWN_PRIM_FIRST
+      // the lanes whose rays ended in the set-up are free again: when enough of them are, take more items first
+      if (!exhausted && (uint32_t)__popcll(__ballot(idle)) >= kRefillIdle) continue;
+#endif
     }
     if (__ballot(!idle) == 0ull) break;
     const uint32_t want_idle = exhausted ? 64u : kRefillIdle;
@@ -1010,8 +1033,10 @@ __global__ void __launch_bounds__(kBlock, 2) k_tail(SceneDev S, RenderConst rc, 
     // ---- one path node per lane ------------------------------------------------------
     NodeOut r;
     r.emitBounce = r.emitMirror = r.emitShade = r.shaded = false;
+    int hprim = -1;
     if (active) {
       Hit h = traverse<false, false, LOCAL>(S, o, d, rc.t_max, stack, tc);
+      hprim = h.prim;
       path_node(S, rc, o, d, T, key, slot, depth, h.prim, h.prim >= 0 ? h.t : 0.0, accum, r);
     }
     // ---- the direct diffuse term (material.cpp:111-130): the shadow rays of the round's shaded hits,
@@ -1033,6 +1058,7 @@ __global__ void __launch_bounds__(kBlock, 2) k_tail(SceneDev S, RenderConst rc, 
             sl.wx[i] = r.W.x; sl.wy[i] = r.W.y; sl.wz[i] = r.W.z;
             sl.key[i] = key;
             sl.slot[i] = slot;
+            sl.prim[i] = (uint32_t)hprim;
           } else {
             bc->overflow = 1;
           }
