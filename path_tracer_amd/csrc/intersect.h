@@ -147,7 +147,13 @@ __device__ __forceinline__ bool analytic_hit(const ObjRec *o, uint32_t kind, d3 
 // no threshold applies.
 __device__ __forceinline__ bool tri_hit(const Tri *tr, d3 org, d3 dir, double &t, double &w1, double &w2, double tfar = 1.0e300,
                                         const ObjRec *lo = nullptr, double t_cap = 0.0, bool recheck = true) {
+#ifdef MIPT_NT_TRI
+  typedef double dbl2_ __attribute__((ext_vector_type(2)));
+  struct NtView { const dbl2_ *p; __device__ double2 operator[](int k) const { dbl2_ v = __builtin_nontemporal_load(p + k); return double2{v.x, v.y}; } };
+  const NtView w{reinterpret_cast<const dbl2_ *>(tr)};
+#else
   const double2 *w = reinterpret_cast<const double2 *>(tr);
+#endif
   const double2 w0 = w[0], w1_ = w[1], w2_ = w[2];  // one round trip for the plane
   d3 n{w0.x, w0.y, w1_.x};
   double denom = dot(n, dir);

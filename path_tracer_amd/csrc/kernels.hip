@@ -190,10 +190,10 @@ __global__ void __launch_bounds__(kBlock) k_generate(SceneDev S, RenderConst rc,
 // for and rays that are neighbours in the queue still enter a wave together; the last quarter
 // of the rounds comes from per-XCD counters so that the waves finish together (WorkFeed).
 #ifndef MIPT_REFILL_IDLE
-#define MIPT_REFILL_IDLE 32
+#define MIPT_REFILL_IDLE 40  // measured 24 / 32 / 40 / 48: 602 / 582 / 577 / 606 ms of k_shadow_any per benchmark step
 #endif
 #ifndef MIPT_REFILL_IDLE_CLOSEST
-#define MIPT_REFILL_IDLE_CLOSEST MIPT_REFILL_IDLE
+#define MIPT_REFILL_IDLE_CLOSEST 32
 #endif
 #ifndef MIPT_OWN_PRIM_FIRST
 #define MIPT_OWN_PRIM_FIRST 1  // any-hit shadow rays that start into their own surface test the primitive they start on first
@@ -695,8 +695,13 @@ __global__ void __launch_bounds__(kBlock, MIPT_TRAV_WAVES) k_shadow_any(SceneDev
           uint32_t h = first_hit + hl;
           int li = light_of_ray(S, r);
           const LightRec &L = S.lights[li];
+#ifdef MIPT_NT_IO
+          d3 P{__builtin_nontemporal_load(sl.px + h), __builtin_nontemporal_load(sl.py + h), __builtin_nontemporal_load(sl.pz + h)};
+          d3 N{__builtin_nontemporal_load(sl.nx + h), __builtin_nontemporal_load(sl.ny + h), __builtin_nontemporal_load(sl.nz + h)};
+#else
           d3 P{sl.px[h], sl.py[h], sl.pz[h]};
           d3 N{sl.nx[h], sl.ny[h], sl.nz[h]};
+#endif
           d3 fire = P + (N * MIPT_RAY_EPSILON) * 3.0;  // material.cpp:117
           ShadowSetup su = shadow_setup(rc, L, li, (int)r - L.first_ray, fire, sl.key[h]);
           scale = su.scale;
@@ -712,6 +717,7 @@ __global__ void __launch_bounds__(kBlock, MIPT_TRAV_WAVES) k_shadow_any(SceneDev
             if (COUNT) tc.prims++;
             if (prim_test<true, LOCAL>(T, S, sl.prim[h])) {
               vis[item] = 0.0;
+              T.cur = MIPT_TRAV_DONE;
               idle = true;
             }
           }
@@ -728,7 +734,11 @@ __global__ void __launch_bounds__(kBlock, MIPT_TRAV_WAVES) k_shadow_any(SceneDev
     do {
       trav_round<true, COUNT, LOCAL>(T, S, stack, tc);
       if (!idle && T.cur == MIPT_TRAV_DONE) {
+#ifdef MIPT_NT_IO
+        __builtin_nontemporal_store(T.best.prim >= 0 ? 0.0 : scale, vis + item);
+#else
         vis[item] = T.best.prim >= 0 ? 0.0 : scale;
+#endif
         idle = true;
       }
     } while ((uint32_t)__popcll(__ballot(idle)) < want_idle);
