@@ -198,6 +198,9 @@ __global__ void __launch_bounds__(kBlock) k_generate(SceneDev S, RenderConst rc,
 #ifndef MIPT_OWN_PRIM_FIRST
 #define MIPT_OWN_PRIM_FIRST 1  // any-hit shadow rays that start into their own surface test the primitive they start on first
 #endif
+#ifndef MIPT_REREFILL_IDLE
+#define MIPT_REREFILL_IDLE 8  // (measured 8 / 16 / 24 / 40: 571.5 / 574.6 / 576.8 / 575.6 ms) lanes idle again right after a refill (rays ended in the set-up) that trigger another one at once
+#endif
 constexpr uint32_t kRefillIdle = MIPT_REFILL_IDLE;                  // shadow rays
 constexpr uint32_t kRefillIdleClosest = MIPT_REFILL_IDLE_CLOSEST;  // path rays
 
@@ -726,7 +729,7 @@ __global__ void __launch_bounds__(kBlock, MIPT_TRAV_WAVES) k_shadow_any(SceneDev
       }
 #if MIPT_OWN_PRIM_FIRST
       // the lanes whose rays ended in the set-up are free again: when enough of them are, take more items first
-      if (!exhausted && (uint32_t)__popcll(__ballot(idle)) >= kRefillIdle) continue;
+      if (!exhausted && (uint32_t)__popcll(__ballot(idle)) >= (uint32_t)MIPT_REREFILL_IDLE) continue;
 #endif
     }
     if (__ballot(!idle) == 0ull) break;
