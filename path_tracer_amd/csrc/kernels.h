@@ -37,11 +37,14 @@ struct DeviceCounters {
   unsigned int dyn_next[8];                         // per-XCD work counters of the running persistent kernel's dynamic tail (not a statistic)
 };
 
+// The two append counters take one atomic each from every block of k_shade; they sit in cache lines of
+// their own, 256 bytes apart, so that the two streams of atomics do not queue behind each other.
 struct BatchCounts {
   uint32_t next_rays;  // entries appended to the next queue
+  uint32_t pad0[63];
   uint32_t shades;     // entries appended to the shade list
   uint32_t overflow;   // a queue was full
-  uint32_t pad;
+  uint32_t pad1[62];
 };
 
 struct RenderConst {

@@ -49,15 +49,20 @@ __device__ __forceinline__ void block_append3(bool a, bool b, bool c, uint32_t *
     cnt[2][w] = (uint32_t)__popcll(mc);
   }
   __syncthreads();
+  static_assert(BLOCK >= 128, "the two reservations are made by the first lanes of two waves");
   if (threadIdx.x == 0) {
-    uint32_t ta = 0, tb = 0, tc = 0;
+    uint32_t ta = 0, tb = 0;
     for (int k = 0; k < W; k++) {
       uint32_t x = cnt[0][k]; cnt[0][k] = ta; ta += x;
       uint32_t y = cnt[1][k]; cnt[1][k] = tb; tb += y;
-      uint32_t z = cnt[2][k]; cnt[2][k] = tc; tc += z;
     }
     for (int k = 0; k < W; k++) cnt[1][k] += ta;  // stream b follows stream a in the shared region
     base[0] = (ta + tb) ? atomicAdd(ca, ta + tb) : 0u;
+  } else if (threadIdx.x == 64) {  // the other counter from another wave: the two round trips overlap
+    uint32_t tc = 0;
+    for (int k = 0; k < W; k++) {
+      uint32_t z = cnt[2][k]; cnt[2][k] = tc; tc += z;
+    }
     base[1] = tc ? atomicAdd(cc, tc) : 0u;
   }
   __syncthreads();
@@ -196,7 +201,7 @@ __global__ void __launch_bounds__(kBlock) k_generate(SceneDev S, RenderConst rc,
 #define MIPT_REFILL_IDLE_CLOSEST 32
 #endif
 #ifndef MIPT_OWN_PRIM_FIRST
-#define MIPT_OWN_PRIM_FIRST 1  // any-hit shadow rays that start into their own surface test the primitive they start on first
+#define MIPT_OWN_PRIM_FIRST 1  // any-hit shadow rays that start into their own surface test the triangle they start on first
 #endif
 #ifndef MIPT_REREFILL_IDLE
 #define MIPT_REREFILL_IDLE 8  // (measured 8 / 16 / 24 / 40: 571.5 / 574.6 / 576.8 / 575.6 ms) lanes idle again right after a refill (rays ended in the set-up) that trigger another one at once
@@ -481,7 +486,12 @@ __device__ __forceinline__ void path_node(const SceneDev &S, const RenderConst &
 }
 
 template <bool COUNT, bool CAM>
-__global__ void __launch_bounds__(kShadeBlock) k_shade(SceneDev S, RenderConst rc, RayQueue q, uint32_t n, uint32_t dup, const double *__restrict__ hit_t,
+#ifdef MIPT_SHADE_WAVES
+#define MIPT_SHADE_BOUNDS __launch_bounds__(kShadeBlock, MIPT_SHADE_WAVES)
+#else
+#define MIPT_SHADE_BOUNDS __launch_bounds__(kShadeBlock)
+#endif
+__global__ void MIPT_SHADE_BOUNDS k_shade(SceneDev S, RenderConst rc, RayQueue q, uint32_t n, uint32_t dup, const double *__restrict__ hit_t,
                                                    const int *__restrict__ hit_prim, RayQueue nq, ShadeList sl, BatchCounts *bc,
                                                    double *accum, DeviceCounters *dc, CameraRays cam) {
   uint32_t idx = blockIdx.x * kShadeBlock + threadIdx.x;
@@ -712,11 +722,13 @@ __global__ void __launch_bounds__(kBlock, MIPT_TRAV_WAVES) k_shadow_any(SceneDev
           idle = false;
 #if MIPT_OWN_PRIM_FIRST
           // A ray that leaves toward the far side of its own surface starts 3e-8 above it and
-          // crosses it at once: the primitive the hit lies on is its occluder.  Testing that
-          // primitive first ends such a ray without a walk; any primitive closer than the light
+          // crosses it at once: the triangle the hit lies on is its occluder.  Testing that
+          // triangle first ends such a ray without a walk; any primitive closer than the light
           // blocks the ray, so which one is found does not matter.  A ray it does not block
-          // (a hit near an edge, a smooth normal on the other side) walks as usual.
-          if (dot(N, su.dir) < 0.0) {
+          // (a hit near an edge, a smooth normal on the other side) walks as usual.  Hits on
+          // analytic primitives walk: their test costs more than the short walks of the small
+          // scenes they make up (spheres.json 665 -> 634 Msamples/s with it, 661 without).
+          if (dot(N, su.dir) < 0.0 && sl.prim[h] >= (uint32_t)S.n_analytic) {
             if (COUNT) tc.prims++;
             if (prim_test<true, LOCAL>(T, S, sl.prim[h])) {
               vis[item] = 0.0;
