@@ -749,6 +749,7 @@ static int render_core(mipt_ctx *c, const mipt_params *p, double *d_sum, hipStre
         // Few rays left in a mesh scene: one launch follows their trees to the end, closest hits and shading only,
         // and hands its shaded hits over as one level's worth would be; the shadow kernels then run once for all of
         // them.  Its waves work `fuse_budget` rounds at most, which bounds what they can append to the list.
+        const bool cam_level = dup > 1;  // the camera rays of a batch of several samples per pixel: one ray and at most one hit per sample
         uint32_t fuse_budget = 0;
         if (halves && dup == 1 && spilled == 0 && n <= c->fuse_rays && (uint64_t)5 * n + 2048 <= cap)
           fuse_budget = (uint32_t)std::min<uint64_t>(4096, rc_l.shade_capacity / ((uint64_t)tail_grid(rc, n) * 256u));
@@ -795,7 +796,7 @@ static int render_core(mipt_ctx *c, const mipt_params *p, double *d_sum, hipStre
           }
           {
             ProfScope ps(c, prof, MIPT_K_SHADOW_SUM, nh, sb);
-            launch_shadow_sum(c->dev, sl_l, h0, nh, vis, accum, sb);
+            launch_shadow_sum(c->dev, sl_l, h0, nh, vis, accum, cam_level && !halves, sb);
           }
         }
         if (halves && h.shades) {

@@ -77,6 +77,16 @@ __device__ __forceinline__ void wave_count(unsigned long long *dst, uint32_t v) 
   if (lane_id() == 0 && v) atomicAdd(dst, (unsigned long long)v);
 }
 
+// The same addition where no other thread of the launch, and no other launch running beside it, touches
+// the slot: the camera rays of a batch (one per sample) and their shaded hits.  A plain read-add-write
+// gives the bits the atomic would (one addition to the same value); the atomics of the fp64 adder in L2
+// are what bounds k_shadow_sum (31 -> 22 ms per benchmark step without them).
+__device__ __forceinline__ void deposit_alone(double *accum, uint32_t slot, d3 v) {
+  double *a = accum + 3ull * slot;
+  if (v.x != 0.0) a[0] = a[0] + v.x;
+  if (v.y != 0.0) a[1] = a[1] + v.y;
+  if (v.z != 0.0) a[2] = a[2] + v.z;
+}
 __device__ __forceinline__ void deposit(double *accum, uint32_t slot, d3 v) {
   double *a = accum + 3ull * slot;
   if (v.x != 0.0) unsafeAtomicAdd(a + 0, v.x);
@@ -383,13 +393,14 @@ struct NodeOut {
   d3 wdir, rdir;   // bounce and mirror directions
   d3 Tb, Tm;       // their throughputs
 };
+template <bool ALONE = false>  // ALONE: the ray is the only one of its sample in this launch (deposit_alone)
 __device__ __forceinline__ void path_node(const SceneDev &S, const RenderConst &rc, d3 o, d3 d, d3 T, uint64_t key, uint32_t slot, int depth, int prim,
                                           double t, double *accum, NodeOut &r) {
   r.emitBounce = r.emitMirror = r.emitShade = r.shaded = false;
   r.P = r.N = r.W = r.wdir = r.rdir = r.Tb = r.Tm = d3{0, 0, 0};
   if (prim < 0) {
     // miss branch, RayTracer.cpp:279-304
-    if (S.has_cubemap) deposit(accum, slot, T * cube_color(S, d));
+    if (S.has_cubemap) { if (ALONE) deposit_alone(accum, slot, T * cube_color(S, d)); else deposit(accum, slot, T * cube_color(S, d)); }
     return;
   }
   double u0 = u01(mix64(key, SLOT_RR));
@@ -454,7 +465,8 @@ __device__ __forceinline__ void path_node(const SceneDev &S, const RenderConst &
     d3 spec = ((F * D) * G) / (4 * nl * nV);
     A = A + (spec * nl) * distance_attenuation(L, P);
   }
-  deposit(accum, slot, (T * A) / norm);
+  if (ALONE) deposit_alone(accum, slot, (T * A) / norm);
+  else deposit(accum, slot, (T * A) / norm);
   // indirect coefficient, material.cpp:146-163: B = kd*|n.w|/pi*(1-m) + F*G*D/(4*|n.w|*(n.V))*|n.w|
   {
     d3 H = normalize(wdir + V);
@@ -520,7 +532,7 @@ __global__ void MIPT_SHADE_BOUNDS k_shade(SceneDev S, RenderConst rc, RayQueue q
       slot = q.slot[idx];
       depth = (int)q.depth[idx];
     }
-    path_node(S, rc, o, d, T, key, slot, depth, prim, prim >= 0 ? hit_t[hidx] : 0.0, accum, r);
+    path_node<CAM>(S, rc, o, d, T, key, slot, depth, prim, prim >= 0 ? hit_t[hidx] : 0.0, accum, r);  // CAM: one camera ray per sample
   }
   const bool emitBounce = r.emitBounce, emitMirror = r.emitMirror, emitShade = r.emitShade, shaded = r.shaded;
   const d3 P = r.P, N = r.N, W = r.W, wdir = r.wdir, rdir = r.rdir, Tb = r.Tb, Tm = r.Tm;
@@ -833,6 +845,7 @@ constexpr int kSumTileRays = 32;
 #ifndef MIPT_SUM_UNTILED
 #define MIPT_SUM_UNTILED 0  // 1: the lane-per-hit kernel for every scene (A/B builds)
 #endif
+template <bool ALONE>  // ALONE: every hit of the launch belongs to another sample (the hits of the camera rays)
 __global__ void __launch_bounds__(kBlock) k_shadow_sum_tiled(SceneDev S, ShadeList sl, uint32_t first_hit, uint32_t n_hits,
                                                               const double *__restrict__ vis, double *accum) {
   extern __shared__ double vis_tile[];
@@ -858,7 +871,8 @@ __global__ void __launch_bounds__(kBlock) k_shadow_sum_tiled(SceneDev S, ShadeLi
     double f = distance_attenuation(L, P) * fabs(dot(N, light_direction(L, P)));
     total = total + (sum * f) * Wt;
   }
-  deposit(accum, sl.slot[h], total);
+  if (ALONE) deposit_alone(accum, sl.slot[h], total);
+  else deposit(accum, sl.slot[h], total);
 }
 
 // The same sum for scenes with many lights, one lane per (hit, light): a lane-per-hit loop walks
@@ -1336,7 +1350,7 @@ void launch_shadow_trace(const SceneDev &S, const RenderConst &rc, ShadeList sl,
   }
 }
 
-void launch_shadow_sum(const SceneDev &S, ShadeList sl, uint64_t first_hit, uint32_t n_hits, const double *vis, double *accum, hipStream_t st) {
+void launch_shadow_sum(const SceneDev &S, ShadeList sl, uint64_t first_hit, uint32_t n_hits, const double *vis, double *accum, bool alone, hipStream_t st) {
   if (!n_hits || !S.rays_per_hit) return;
   if (!S.translucent && S.n_lights > 4) {
     hipLaunchKernelGGL(k_shadow_sum_lights, dim3(grid_for((uint64_t)n_hits * (uint64_t)S.n_lights)), dim3(kBlock), 0, st, S, sl, (uint32_t)first_hit,
@@ -1344,8 +1358,8 @@ void launch_shadow_sum(const SceneDev &S, ShadeList sl, uint64_t first_hit, uint
     return;
   }
   if (!S.translucent && S.rays_per_hit <= kSumTileRays && !MIPT_SUM_UNTILED) {
-    hipLaunchKernelGGL(k_shadow_sum_tiled, dim3(grid_for(n_hits)), dim3(kBlock), (size_t)kBlock * S.rays_per_hit * sizeof(double), st, S, sl,
-                       (uint32_t)first_hit, n_hits, vis, accum);
+    hipLaunchKernelGGL(alone ? k_shadow_sum_tiled<true> : k_shadow_sum_tiled<false>, dim3(grid_for(n_hits)), dim3(kBlock),
+                       (size_t)kBlock * S.rays_per_hit * sizeof(double), st, S, sl, (uint32_t)first_hit, n_hits, vis, accum);
     return;
   }
   auto kern = S.translucent ? k_shadow_sum<true> : k_shadow_sum<false>;
