@@ -274,6 +274,47 @@ def test_mesh_scene_images(gpu, oracle_lib):
     assert_images_match(f32, ref, rgb8, ref8)
 
 
+def test_shadow_rays_into_their_own_surface(gpu, oracle_lib):
+    """shadeBRDF fires a shadow ray toward every light, also one behind the surface (material.cpp:117-126);
+    such a ray starts 3e-8 above the triangle it leaves and crosses it at once.  The shadow kernel ends it
+    with a test of that triangle instead of a walk.  Lights below the terrain and inside the blob layer:
+    most shadow rays of mesh hits are of that kind.  The frames must stay the oracle's (flat and smooth
+    normals, hits next to edges included), and the walks must be gone from the counters."""
+    import copy
+
+    from path_tracer_amd import synth
+
+    base = synth.make_scene(20000, seed=7)
+    low = copy.deepcopy(base)
+    for L in low.lights:
+        if L.type == abi.LIGHT_RECT_AREA:
+            L.position = np.array([-6.0, -30.0, -40.0])  # below terrain and floor: every mesh hit seen from above faces away
+        else:
+            L.direction = np.array([0.3, 1.0, 0.2])      # shines upward
+    mid = copy.deepcopy(base)
+    for L in mid.lights:
+        if L.type == abi.LIGHT_RECT_AREA:
+            L.position = np.array([-6.0, 1.0, -40.0])    # among the blobs: grazing and back-facing hits mixed
+    per_ray = {}
+    for name, sc in (("base", base), ("low", low), ("mid", mid)):
+        upload(gpu, sc)
+        orc = oracle_lib.Oracle(sc)
+        p = abi.default_params(128, 72, spp=2)
+        f32, rgb8 = gpu.render(p)
+        ref, ref8 = orc.render(p, threads=8, want_rgb8=True)
+        assert_images_match(f32, ref, rgb8, ref8)
+        gpu.reset_counters()
+        pc = abi.default_params(128, 72, spp=2, flags=abi.FLAG_COUNTERS)
+        f32c, _ = gpu.render(pc, want_rgb8=False)
+        assert np.array_equal(f32c, f32)
+        c = gpu.counters()
+        assert c["shadow_rays"] > 0
+        per_ray[name] = c["shadow_node_visits"] / c["shadow_rays"]
+    # lights behind every mesh surface: what is left are the walks from the analytic floor and the few
+    # rays their own triangle does not block
+    assert per_ray["low"] < 0.25 * per_ray["base"], per_ray
+
+
 def test_cull_negligible_flag_skips_rays_without_changing_the_image(gpu, oracle_lib):
     """MIPT_FLAG_CULL_NEGLIGIBLE drops the shadow rays of hits on "metallic 1" materials (diffuse
     weight 1.1e-16 after material.cpp:232-241) and nothing else: fewer shadow rays, the same
