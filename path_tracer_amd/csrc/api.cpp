@@ -582,6 +582,10 @@ int mipt_upload_scene(mipt_ctx *c, const mipt_scene_desc *desc) {
     }
   }
   D.translucent = H.translucent ? 1 : 0;
+  D.vis_bytes = (!H.translucent && H.flat_lights) ? 1 : 0;
+  if (const char *e = std::getenv("MIPT_VIS_BYTES")) {  // measurement knob: 0 keeps the fp64 visibility records
+    if (std::atoi(e) == 0) D.vis_bytes = 0;
+  }
   D.local_meshes = H.local_meshes ? 1 : 0;
   D.t_cap = 1000.0;  // every entry point that traces sets it to its own t_max
   D.radius = H.radius;

@@ -42,6 +42,7 @@ struct SceneDev {
   uint32_t *stack_ovf;     // overflow of the traversal stacks: entry k of thread g at [k * ovf_stride + g]
   uint32_t ovf_stride;     // threads the overflow area is laid out for
   int translucent;
+  int vis_bytes;  // opaque scene whose lights are all flat: a shadow ray's result is one byte (reached its light or not)
   int local_meshes;  // some mesh object has ObjRec::local_units set: triangle tests look their object up
   double t_cap;      // the render's t_max: the cap Trimesh::intersectLocal starts every mesh walk with, in LOCAL units (trimesh.cpp:85-86)
   double radius;
@@ -147,13 +148,7 @@ __device__ __forceinline__ bool analytic_hit(const ObjRec *o, uint32_t kind, d3 
 // no threshold applies.
 __device__ __forceinline__ bool tri_hit(const Tri *tr, d3 org, d3 dir, double &t, double &w1, double &w2, double tfar = 1.0e300,
                                         const ObjRec *lo = nullptr, double t_cap = 0.0, bool recheck = true) {
-#ifdef MIPT_NT_TRI
-  typedef double dbl2_ __attribute__((ext_vector_type(2)));
-  struct NtView { const dbl2_ *p; __device__ double2 operator[](int k) const { dbl2_ v = __builtin_nontemporal_load(p + k); return double2{v.x, v.y}; } };
-  const NtView w{reinterpret_cast<const dbl2_ *>(tr)};
-#else
   const double2 *w = reinterpret_cast<const double2 *>(tr);
-#endif
   const double2 w0 = w[0], w1_ = w[1], w2_ = w[2];  // one round trip for the plane
   d3 n{w0.x, w0.y, w1_.x};
   double denom = dot(n, dir);

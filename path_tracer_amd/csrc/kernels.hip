@@ -685,7 +685,9 @@ __device__ __forceinline__ int light_of_ray(const SceneDev &S, uint32_t r) {
 // Any-hit shadow rays for opaque scenes, persistent waves with ray replacement (see
 // k_intersect).  Work item w = hit * rays_per_hit + ray, hits counted from `first_hit`: the
 // rays of one hit are adjacent and enter a wave together, so they share origin and target
-// region.  Result per ray: vis[w] = 0 if occluded, else the sample's attenuation scale.
+// region.  Result per ray: vis[w] = 0 if occluded, else the sample's attenuation scale; in scenes whose lights
+// all have a sample-independent scale (SceneDev::vis_bytes) one byte per ray instead, 0 or 1, and the sum
+// kernels put the light's scale in: an eighth of the bytes written here and read there.
 template <bool COUNT, bool LOCAL>
 __global__ void __launch_bounds__(kBlock, MIPT_TRAV_WAVES) k_shadow_any(SceneDev S, RenderConst rc, ShadeList sl, uint32_t first_hit, uint32_t n_items,
                                                                          double *__restrict__ vis, DeviceCounters *dc) {
@@ -720,13 +722,8 @@ __global__ void __launch_bounds__(kBlock, MIPT_TRAV_WAVES) k_shadow_any(SceneDev
           uint32_t h = first_hit + hl;
           int li = light_of_ray(S, r);
           const LightRec &L = S.lights[li];
-#ifdef MIPT_NT_IO
-          d3 P{__builtin_nontemporal_load(sl.px + h), __builtin_nontemporal_load(sl.py + h), __builtin_nontemporal_load(sl.pz + h)};
-          d3 N{__builtin_nontemporal_load(sl.nx + h), __builtin_nontemporal_load(sl.ny + h), __builtin_nontemporal_load(sl.nz + h)};
-#else
           d3 P{sl.px[h], sl.py[h], sl.pz[h]};
           d3 N{sl.nx[h], sl.ny[h], sl.nz[h]};
-#endif
           d3 fire = P + (N * MIPT_RAY_EPSILON) * 3.0;  // material.cpp:117
           ShadowSetup su = shadow_setup(rc, L, li, (int)r - L.first_ray, fire, sl.key[h]);
           scale = su.scale;
@@ -743,7 +740,8 @@ __global__ void __launch_bounds__(kBlock, MIPT_TRAV_WAVES) k_shadow_any(SceneDev
           if (dot(N, su.dir) < 0.0 && sl.prim[h] >= (uint32_t)S.n_analytic) {
             if (COUNT) tc.prims++;
             if (prim_test<true, LOCAL>(T, S, sl.prim[h])) {
-              vis[item] = 0.0;
+              if (S.vis_bytes) reinterpret_cast<uint8_t *>(vis)[item] = 0;
+              else vis[item] = 0.0;
               T.cur = MIPT_TRAV_DONE;
               idle = true;
             }
@@ -761,11 +759,8 @@ __global__ void __launch_bounds__(kBlock, MIPT_TRAV_WAVES) k_shadow_any(SceneDev
     do {
       trav_round<true, COUNT, LOCAL>(T, S, stack, tc);
       if (!idle && T.cur == MIPT_TRAV_DONE) {
-#ifdef MIPT_NT_IO
-        __builtin_nontemporal_store(T.best.prim >= 0 ? 0.0 : scale, vis + item);
-#else
-        vis[item] = T.best.prim >= 0 ? 0.0 : scale;
-#endif
+        if (S.vis_bytes) reinterpret_cast<uint8_t *>(vis)[item] = T.best.prim >= 0 ? 0 : 1;
+        else vis[item] = T.best.prim >= 0 ? 0.0 : scale;
         idle = true;
       }
     } while ((uint32_t)__popcll(__ballot(idle)) < want_idle);
@@ -875,6 +870,32 @@ __global__ void __launch_bounds__(kBlock) k_shadow_sum_tiled(SceneDev S, ShadeLi
   else deposit(accum, sl.slot[h], total);
 }
 
+// The same sum from one-byte visibility records (SceneDev::vis_bytes): a lane reads its hit's rays_per_hit
+// bytes, which lie side by side with its neighbours' (no staging through LDS), and adds the light's scale
+// for every ray that reached it: the additions, and their order, of the fp64 records' sum.
+template <bool ALONE>
+__global__ void __launch_bounds__(kBlock) k_shadow_sum_bytes(SceneDev S, ShadeList sl, uint32_t first_hit, uint32_t n_hits,
+                                                              const uint8_t *__restrict__ vis8, double *accum) {
+  uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n_hits) return;
+  const uint32_t h = first_hit + i;
+  d3 P{sl.px[h], sl.py[h], sl.pz[h]};
+  d3 N{sl.nx[h], sl.ny[h], sl.nz[h]};
+  d3 Wt{sl.wx[h], sl.wy[h], sl.wz[h]};
+  const uint8_t *v = vis8 + (uint64_t)i * (uint32_t)S.rays_per_hit;
+  d3 total{0, 0, 0};
+  for (int li = 0; li < S.n_lights; li++) {
+    const LightRec &L = S.lights[li];
+    d3 sum{0, 0, 0};
+    for (int s = 0; s < L.samples; s++) sum = sum + ld3(L.color) * (v[L.first_ray + s] ? L.flat_scale : 0.0);
+    if (L.type == MIPT_LIGHT_RECT_AREA) sum = sum / (double)L.samples;  // light.cpp:145
+    double f = distance_attenuation(L, P) * fabs(dot(N, light_direction(L, P)));
+    total = total + (sum * f) * Wt;
+  }
+  if (ALONE) deposit_alone(accum, sl.slot[h], total);
+  else deposit(accum, sl.slot[h], total);
+}
+
 // The same sum for scenes with many lights, one lane per (hit, light): a lane-per-hit loop walks
 // rays_per_hit doubles at a stride of rays_per_hit doubles between lanes, which wastes most of
 // every cache line when there are hundreds of rays per hit.  Here adjacent lanes read adjacent
@@ -891,9 +912,14 @@ __global__ void __launch_bounds__(kBlock) k_shadow_sum_lights(SceneDev S, ShadeL
   if (live) {
     const uint32_t li = (uint32_t)(item - (uint64_t)i * nL);
     const LightRec &L = S.lights[li];
-    const double *v = vis + (uint64_t)i * (uint32_t)S.rays_per_hit + (uint32_t)L.first_ray;
     double sum = 0.0;
-    for (int s = 0; s < L.samples; s++) sum += v[s];
+    if (S.vis_bytes) {
+      const uint8_t *v8 = reinterpret_cast<const uint8_t *>(vis) + (uint64_t)i * (uint32_t)S.rays_per_hit + (uint32_t)L.first_ray;
+      for (int s = 0; s < L.samples; s++) sum += v8[s] ? L.flat_scale : 0.0;
+    } else {
+      const double *v = vis + (uint64_t)i * (uint32_t)S.rays_per_hit + (uint32_t)L.first_ray;
+      for (int s = 0; s < L.samples; s++) sum += v[s];
+    }
     d3 col = ld3(L.color) * sum;
     if (L.type == MIPT_LIGHT_RECT_AREA) col = col / (double)L.samples;  // light.cpp:145
     d3 P{sl.px[h], sl.py[h], sl.pz[h]};
@@ -1355,6 +1381,11 @@ void launch_shadow_sum(const SceneDev &S, ShadeList sl, uint64_t first_hit, uint
   if (!S.translucent && S.n_lights > 4) {
     hipLaunchKernelGGL(k_shadow_sum_lights, dim3(grid_for((uint64_t)n_hits * (uint64_t)S.n_lights)), dim3(kBlock), 0, st, S, sl, (uint32_t)first_hit,
                        n_hits, vis, accum);
+    return;
+  }
+  if (S.vis_bytes) {
+    hipLaunchKernelGGL(alone ? k_shadow_sum_bytes<true> : k_shadow_sum_bytes<false>, dim3(grid_for(n_hits)), dim3(kBlock), 0, st, S, sl,
+                       (uint32_t)first_hit, n_hits, reinterpret_cast<const uint8_t *>(vis), accum);
     return;
   }
   if (!S.translucent && S.rays_per_hit <= kSumTileRays && !MIPT_SUM_UNTILED) {

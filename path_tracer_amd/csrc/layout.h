@@ -116,7 +116,7 @@ struct alignas(8) LightRec {
   int32_t type;
   int32_t samples;      // shadow rays this light fires per shading point
   int32_t first_ray;    // offset of its first ray in the per-hit shadow-ray block
-  int32_t pad;
+  int32_t flat;         // the attenuation of its shadow rays does not depend on the sample: flat_scale
   double color[3];
   double position[3];     // point: position; area: corner
   double orientation[3];  // directional: normalised orientation (light.h:46)
@@ -124,6 +124,7 @@ struct alignas(8) LightRec {
   double center[3];       // area: light.h:124
   double uL, vL;
   double a, b, c;         // attenuation coefficients (float in the reference, widened)
+  double flat_scale;      // flat: min(1, 1/denom) of light.cpp:139-142 with b = c = 0 (1 for point and directional lights)
 };
 
 struct CameraRec {

@@ -616,6 +616,17 @@ int build_host_scene(const mipt_scene_desc *d, HostScene *out, std::string *err,
     L.a = (double)src.atten[0];
     L.b = (double)src.atten[1];
     L.c = (double)src.atten[2];
+    // The per-sample attenuation of an area light, min(1, 1 / (a + b d + c d^2)) (light.cpp:139-142), is the
+    // same for every sample when b = c = 0: the products are zeros at any finite distance d, evaluated here
+    // with the expression the kernels use.  Point and directional shadow rays carry no such factor.
+    L.flat = 1;
+    L.flat_scale = 1.0;
+    if (src.type == MIPT_LIGHT_RECT_AREA) {
+      const double d1 = 1.0;
+      L.flat = (L.b == 0.0 && L.c == 0.0) ? 1 : 0;
+      L.flat_scale = std::fmin(1.0, 1 / (L.a + L.b * d1 + L.c * (d1 * d1)));
+    }
+    if (!L.flat) S.flat_lights = false;
     S.lights.push_back(L);
   }
 

@@ -32,6 +32,7 @@ struct HostScene {
   int stack_need = 0;                  // most entries a traversal can hold on its stack at once
   double radius = 0;                   // max |coordinate| of the scene bounds
   bool translucent = false;            // some material has kt != 0
+  bool flat_lights = true;             // every light's shadow rays have a sample-independent attenuation (LightRec::flat)
   bool local_meshes = false;           // some mesh object has ObjRec::local_units set
   bool has_cubemap = false;
   int cube_w[6], cube_h[6];
