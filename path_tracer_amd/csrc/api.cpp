@@ -582,9 +582,12 @@ int mipt_upload_scene(mipt_ctx *c, const mipt_scene_desc *desc) {
     }
   }
   D.translucent = H.translucent ? 1 : 0;
-  D.vis_bytes = (!H.translucent && H.flat_lights) ? 1 : 0;
-  if (const char *e = std::getenv("MIPT_VIS_BYTES")) {  // measurement knob: 0 keeps the fp64 visibility records
-    if (std::atoi(e) == 0) D.vis_bytes = 0;
+  // one-byte visibility records where they are exact (see LightRec::flat) and pay: in scenes of a few primitives a
+  // shadow ray's walk is so short that its byte store, which shares a word with its neighbours', costs more than the
+  // sums save (cornellBoxes with an area light: shadow kernel 202 -> 211 ms, sums 26 -> 24)
+  D.vis_bytes = (!H.translucent && H.flat_lights && H.prim_info.size() > 4096) ? 1 : 0;
+  if (const char *e = std::getenv("MIPT_VIS_BYTES")) {  // measurement and test knob: 0 = fp64 records, 1 = bytes wherever they are exact
+    D.vis_bytes = (std::atoi(e) != 0 && !H.translucent && H.flat_lights) ? 1 : 0;
   }
   D.local_meshes = H.local_meshes ? 1 : 0;
   D.t_cap = 1000.0;  // every entry point that traces sets it to its own t_max

@@ -688,7 +688,7 @@ __device__ __forceinline__ int light_of_ray(const SceneDev &S, uint32_t r) {
 // region.  Result per ray: vis[w] = 0 if occluded, else the sample's attenuation scale; in scenes whose lights
 // all have a sample-independent scale (SceneDev::vis_bytes) one byte per ray instead, 0 or 1, and the sum
 // kernels put the light's scale in: an eighth of the bytes written here and read there.
-template <bool COUNT, bool LOCAL>
+template <bool COUNT, bool LOCAL, bool VIS8>  // VIS8: one-byte records (a kernel of its own: the fp64 one keeps its code and registers)
 __global__ void __launch_bounds__(kBlock, MIPT_TRAV_WAVES) k_shadow_any(SceneDev S, RenderConst rc, ShadeList sl, uint32_t first_hit, uint32_t n_items,
                                                                          double *__restrict__ vis, DeviceCounters *dc) {
   extern __shared__ uint32_t lds_stack[];
@@ -740,7 +740,7 @@ __global__ void __launch_bounds__(kBlock, MIPT_TRAV_WAVES) k_shadow_any(SceneDev
           if (dot(N, su.dir) < 0.0 && sl.prim[h] >= (uint32_t)S.n_analytic) {
             if (COUNT) tc.prims++;
             if (prim_test<true, LOCAL>(T, S, sl.prim[h])) {
-              if (S.vis_bytes) reinterpret_cast<uint8_t *>(vis)[item] = 0;
+              if (VIS8) reinterpret_cast<uint8_t *>(vis)[item] = 0;
               else vis[item] = 0.0;
               T.cur = MIPT_TRAV_DONE;
               idle = true;
@@ -759,7 +759,7 @@ __global__ void __launch_bounds__(kBlock, MIPT_TRAV_WAVES) k_shadow_any(SceneDev
     do {
       trav_round<true, COUNT, LOCAL>(T, S, stack, tc);
       if (!idle && T.cur == MIPT_TRAV_DONE) {
-        if (S.vis_bytes) reinterpret_cast<uint8_t *>(vis)[item] = T.best.prim >= 0 ? 0 : 1;
+        if (VIS8) reinterpret_cast<uint8_t *>(vis)[item] = T.best.prim >= 0 ? 0 : 1;
         else vis[item] = T.best.prim >= 0 ? 0.0 : scale;
         idle = true;
       }
@@ -1370,7 +1370,11 @@ void launch_shadow_trace(const SceneDev &S, const RenderConst &rc, ShadeList sl,
     auto kern = S.local_meshes ? (count ? k_shadow_walk<true, true> : k_shadow_walk<false, true>) : (count ? k_shadow_walk<true, false> : k_shadow_walk<false, false>);
     hipLaunchKernelGGL(kern, dim3(persistent_grid(rc, items)), dim3(kBlock), stack_bytes(S), st, S, rc, sl, first_hit * R, items, vis, dc);
   } else {
-    auto kern = S.local_meshes ? (count ? k_shadow_any<true, true> : k_shadow_any<false, true>) : (count ? k_shadow_any<true, false> : k_shadow_any<false, false>);
+    auto kern = S.local_meshes ? (count ? k_shadow_any<true, true, false> : k_shadow_any<false, true, false>)
+                               : (count ? k_shadow_any<true, false, false> : k_shadow_any<false, false, false>);
+    if (S.vis_bytes)
+      kern = S.local_meshes ? (count ? k_shadow_any<true, true, true> : k_shadow_any<false, true, true>)
+                            : (count ? k_shadow_any<true, false, true> : k_shadow_any<false, false, true>);
     (void)hipMemsetAsync(dc->dyn_next, 0, sizeof(dc->dyn_next), st);
     hipLaunchKernelGGL(kern, dim3(persistent_grid(rc, items)), dim3(kBlock), stack_bytes(S), st, S, rc, sl, (uint32_t)first_hit, items, vis, dc);
   }

@@ -493,6 +493,37 @@ def test_two_launch_streams_give_the_one_stream_frame(scenes, monkeypatch):
             assert np.abs(other - one).max() <= 1e-6, key  # float32 frames: an ulp at most
 
 
+def test_one_byte_visibility_records_give_the_fp64_records_frame(scenes, monkeypatch):
+    # Where every light's per-sample attenuation is a constant of the light (area lights with b = c = 0, light.cpp:139-142)
+    # a shadow ray's record can be one byte, the sums putting the constant in (the default in scenes of more than 4096
+    # primitives, MIPT_VIS_BYTES=1 everywhere); MIPT_VIS_BYTES=0 keeps the fp64 records.
+    # The additions are the same ones in the same order: the frames agree up to the order of the atomic adds.
+    # (An area light with b or c set uses the fp64 records either way: the second mesh scene.)
+    import copy
+
+    from path_tracer_amd.raytracer import Context
+    curved = synth.make_scene(20000, seed=3)
+    for L in curved.lights:
+        if L.type == abi.LIGHT_RECT_AREA:
+            L.atten = np.array([0.6, 0.02, 0.001], dtype=np.float32)
+    frames = {}
+    for knob in ("1", "0"):
+        monkeypatch.setenv("MIPT_VIS_BYTES", knob)
+        ctx = Context(0)
+        try:
+            for name, sc in (("areaLight", scenes("areaLight")), ("cornell_area", synth.cornell_area_light(copy.deepcopy(scenes("cornellBoxes")))),
+                             ("mesh", synth.make_scene(20000, seed=3)), ("mesh_curved_attenuation", curved)):
+                ctx.upload_scene(sc)
+                for batch in (0, 3000):
+                    p = abi.default_params(96, 96, spp=6, seed=5, batch_samples=batch)
+                    frames.setdefault((name, batch), []).append(ctx.render(p, want_rgb8=False)[0].astype(np.float64))
+        finally:
+            ctx.close()
+    for key, (bytes_, doubles) in frames.items():
+        assert bytes_.max() > 0.05, key
+        assert np.abs(bytes_ - doubles).max() <= 1e-6, key  # float32 frames: an ulp at most
+
+
 # ------------------------------------------------------------------ edge cases
 def test_edge_cases(gpu, oracle_lib):
     empty = U.scene([], lights=[U.dir_light((0, -1, 0))])

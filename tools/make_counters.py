@@ -30,7 +30,7 @@ from path_tracer_amd.buildinfo import kernel_source_hash  # noqa: E402
 
 CLOCK, SIMDS, CUS = 2.4e9, 1024, 256
 KEY = {"k_intersect": "intersect", "k_shadow_any": "shadow", "k_shadow_walk": "shadow", "k_shade": "shade", "k_shadow_sum": "shadow_sum",
-       "k_shadow_sum_lights": "shadow_sum", "k_generate": "generate", "k_resolve": "resolve"}
+       "k_shadow_sum_lights": "shadow_sum", "k_shadow_sum_tiled": "shadow_sum", "k_shadow_sum_bytes": "shadow_sum", "k_generate": "generate", "k_resolve": "resolve"}
 
 
 def kernel_of(name):
