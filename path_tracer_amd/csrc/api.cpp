@@ -554,6 +554,21 @@ int mipt_upload_scene(mipt_ctx *c, const mipt_scene_desc *desc) {
   D.n_materials = (int)H.materials.size();
   D.n_prims = (int)H.prim_info.size();
   D.n_analytic = H.n_analytic;
+  {
+    // world boxes of the objects; in mesh scenes with at most a few analytic primitives the shadow kernel tests
+    // those ahead of its walk, box first, and walks the triangles only
+    const size_t bytes = std::max<size_t>(H.object_boxes.size() * sizeof(double), 16);
+    void *p = nullptr;
+    HIP_TRY(c, hipMalloc(&p, bytes));
+    c->scene_allocs.push_back(p);
+    c->scene_bytes += (int64_t)bytes;
+    if (!H.object_boxes.empty()) HIP_TRY(c, hipMemcpy(p, H.object_boxes.data(), H.object_boxes.size() * sizeof(double), hipMemcpyHostToDevice));
+    D.object_boxes = reinterpret_cast<const double *>(p);
+    D.lean_any = (H.n_analytic <= 8 && (size_t)H.n_analytic < H.prim_info.size()) ? 1 : 0;
+    if (const char *e = std::getenv("MIPT_LEAN_ANY")) {  // measurement knob: 0 keeps the analytic tests in the walk
+      if (std::atoi(e) == 0) D.lean_any = 0;
+    }
+  }
   // traversal stacks: up to kLdsStackMax entries per lane in LDS (6 blocks x 256 lanes x 24
   // entries fill 144 of a CU's 160 KB), the rest of the worst case in global memory
   const int kLdsStackMax = 24;

@@ -37,6 +37,8 @@ struct SceneDev {
   int n_materials;
   int n_prims;
   int n_analytic;  // primitives [0, n_analytic) are analytic, [n_analytic, n_prims) triangles
+  const double *object_boxes;  // per object: world box (min xyz, max xyz), slightly grown
+  int lean_any;    // few analytic primitives beside meshes: any-hit walks test them ahead of the walk (k_shadow_any)
   int rays_per_hit;
   int stack_entries;  // LDS traversal stack entries per lane; deeper entries go to stack_ovf
   uint32_t *stack_ovf;     // overflow of the traversal stacks: entry k of thread g at [k * ovf_stride + g]
@@ -211,6 +213,24 @@ __device__ __forceinline__ Cull make_cull(d3 o, d3 d, double R) {
   return c;
 }
 
+// Can the ray meet the box `b` (min xyz, max xyz) at 0 <= t <= tmax?  May say yes too often, never no.
+__device__ __forceinline__ bool ray_meets_box(d3 o, d3 d, double tmax, const double *b) {
+  double t0 = 0.0, t1 = tmax;
+  const double oo[3] = {o.x, o.y, o.z}, dd[3] = {d.x, d.y, d.z};
+#pragma unroll
+  for (int a = 0; a < 3; a++) {
+    if (dd[a] == 0.0) {
+      if (oo[a] < b[a] || oo[a] > b[3 + a]) return false;
+    } else {
+      const double inv = 1.0 / dd[a];
+      const double ta = (b[a] - oo[a]) * inv, tb = (b[3 + a] - oo[a]) * inv;
+      t0 = fmax(t0, fmin(ta, tb));
+      t1 = fmin(t1, fmax(ta, tb));
+    }
+  }
+  return t0 <= t1 * (1.0 + 1e-12) + 1e-12;
+}
+
 struct Hit {
   double t;
   int prim;  // storage index, -1 = miss
@@ -325,11 +345,12 @@ __device__ __forceinline__ void node_test(const Trav &T, const SceneDev &S, int 
 // smallest (t, ref_order).  Any hit: every t < T.best.t counts.  Returns whether T.best changed.
 // LOCAL: the scene has a mesh with ObjRec::local_units set (SceneDev::local_meshes), so a triangle
 // test looks its object up; scenes without one run kernels compiled without that path.
-template <bool ANY, bool LOCAL>
+// TRI_ONLY: `s` is known to be a triangle (the analytic tests are not compiled in).
+template <bool ANY, bool LOCAL, bool TRI_ONLY = false>
 __device__ __forceinline__ bool prim_test(Trav &T, const SceneDev &S, uint32_t s) {
   double t;
   bool hit;
-  if (s >= (uint32_t)S.n_analytic) {
+  if (TRI_ONLY || s >= (uint32_t)S.n_analytic) {
     double w1, w2;
     if (LOCAL) {
       const ObjRec *o = S.objects + (S.prim_info[s] & 0x3fffffffu);
@@ -359,7 +380,8 @@ __device__ __forceinline__ bool prim_test(Trav &T, const SceneDev &S, uint32_t s
 // Closest hit (ANY = false): children are entered near to far.  Any hit (ANY = true):
 // children are entered in slot order (the builder puts large boxes first) and the first
 // primitive with t < tmax ends the walk.
-template <bool ANY, bool COUNT, bool LOCAL>
+// TRI_ONLY: the leaves' analytic primitives are passed over (the caller has tested them).
+template <bool ANY, bool COUNT, bool LOCAL, bool TRI_ONLY = false>
 __device__ __forceinline__ void trav_round(Trav &T, const SceneDev &S, const Stack &stk, TravCounters &tc) {
   int cur = T.cur, sp = T.sp;
   while (cur >= 0) {
@@ -411,12 +433,13 @@ __device__ __forceinline__ void trav_round(Trav &T, const SceneDev &S, const Sta
     uint32_t first = code >> 3, count = (code & 7u) + 1u;
     bool found = false;
     for (uint32_t k = 0; k < count; k++) {
+      if (TRI_ONLY && first + k < (uint32_t)S.n_analytic) continue;
 #ifdef MIPT_LANE_STATS
       if (COUNT) { unsigned long long m_ = __ballot(1); if (__lane_id() == (unsigned)__ffsll((long long)m_) - 1u) tc.prims += 64; }
 #else
       if (COUNT) tc.prims++;
 #endif
-      if (prim_test<ANY, LOCAL>(T, S, first + k) && ANY) { found = true; break; }
+      if (prim_test<ANY, LOCAL, TRI_ONLY>(T, S, first + k) && ANY) { found = true; break; }
     }
     if (found || sp == 0) cur = MIPT_TRAV_DONE;
     else cur = (int)stack_pop(S, stk, sp);

@@ -688,7 +688,13 @@ __device__ __forceinline__ int light_of_ray(const SceneDev &S, uint32_t r) {
 // region.  Result per ray: vis[w] = 0 if occluded, else the sample's attenuation scale; in scenes whose lights
 // all have a sample-independent scale (SceneDev::vis_bytes) one byte per ray instead, 0 or 1, and the sum
 // kernels put the light's scale in: an eighth of the bytes written here and read there.
-template <bool COUNT, bool LOCAL, bool VIS8>  // VIS8: one-byte records (a kernel of its own: the fp64 one keeps its code and registers)
+// LEAN (SceneDev::lean_any: meshes with at most a few analytic primitives beside them, a floor square say): this
+// kernel passes the analytic primitives over and k_shadow_analytic, launched after it, clears the records of
+// the rays they block — any primitive closer than the light blocks a ray, whichever kernel finds it.  With the
+// sphere, box and square tests compiled into it, anywhere, this kernel is 7 % slower on the benchmark scene
+// (registers), whose one analytic primitive hardly any shadow ray meets.
+constexpr int kLeanAnalyticMax = 8;
+template <bool COUNT, bool LOCAL, bool VIS8, bool LEAN>  // VIS8: one-byte records (a kernel of its own: the fp64 one keeps its code and registers)
 __global__ void __launch_bounds__(kBlock, MIPT_TRAV_WAVES) k_shadow_any(SceneDev S, RenderConst rc, ShadeList sl, uint32_t first_hit, uint32_t n_items,
                                                                          double *__restrict__ vis, DeviceCounters *dc) {
   extern __shared__ uint32_t lds_stack[];
@@ -739,7 +745,7 @@ __global__ void __launch_bounds__(kBlock, MIPT_TRAV_WAVES) k_shadow_any(SceneDev
           // scenes they make up (spheres.json 665 -> 634 Msamples/s with it, 661 without).
           if (dot(N, su.dir) < 0.0 && sl.prim[h] >= (uint32_t)S.n_analytic) {
             if (COUNT) tc.prims++;
-            if (prim_test<true, LOCAL>(T, S, sl.prim[h])) {
+            if (prim_test<true, LOCAL, true>(T, S, sl.prim[h])) {
               if (VIS8) reinterpret_cast<uint8_t *>(vis)[item] = 0;
               else vis[item] = 0.0;
               T.cur = MIPT_TRAV_DONE;
@@ -757,7 +763,7 @@ __global__ void __launch_bounds__(kBlock, MIPT_TRAV_WAVES) k_shadow_any(SceneDev
     if (__ballot(!idle) == 0ull) break;
     const uint32_t want_idle = exhausted ? 64u : kRefillIdle;
     do {
-      trav_round<true, COUNT, LOCAL>(T, S, stack, tc);
+      trav_round<true, COUNT, LOCAL, LEAN>(T, S, stack, tc);
       if (!idle && T.cur == MIPT_TRAV_DONE) {
         if (VIS8) reinterpret_cast<uint8_t *>(vis)[item] = T.best.prim >= 0 ? 0 : 1;
         else vis[item] = T.best.prim >= 0 ? 0.0 : scale;
@@ -768,6 +774,111 @@ __global__ void __launch_bounds__(kBlock, MIPT_TRAV_WAVES) k_shadow_any(SceneDev
   if (COUNT) {
     wave_count(&dc->shadow_nodes, tc.nodes);
     wave_count(&dc->shadow_prims, tc.prims);
+  }
+}
+
+// A light record read through the scalar data path: `p` must be the same for every lane of the wave.  The
+// light table does not change while a kernel runs, which a load through the constant address space tells the
+// compiler (after the first store of a kernel it would otherwise reload the fields lane by lane).
+__device__ __forceinline__ LightRec load_light_uniform(const LightRec *p) {
+  typedef const __attribute__((address_space(4))) uint64_t *ConstWords;
+  ConstWords c = (ConstWords)(uintptr_t)p;
+  LightRec L;
+  uint64_t *d = reinterpret_cast<uint64_t *>(&L);
+  static_assert(sizeof(LightRec) % 8 == 0, "LightRec is copied in 8-byte words");
+#pragma unroll
+  for (int i = 0; i < (int)(sizeof(LightRec) / 8); i++) d[i] = c[i];
+  return L;
+}
+
+// The analytic primitives' share of a LEAN shadow launch, one lane per hit, light after light.  Every shadow ray
+// of a (hit, light) pair runs from the hit's firing point to a point of the light's box of sample points
+// (light.cpp:109), so it stays inside the shaft between the two — at parameter t the box
+// [F + t (B.lo - F), F + t (B.hi - F)] — and a primitive whose (slightly grown) world box the shaft misses blocks
+// none of them: almost every pair ends there, most of them without a division.  For the others the pair's rays
+// are set up as in k_shadow_any and tested against that primitive, and the records of blocked rays are cleared
+// (this launch follows k_shadow_any's on the same stream).
+template <bool LOCAL>
+__global__ void __launch_bounds__(kBlock) k_shadow_analytic(SceneDev S, RenderConst rc, ShadeList sl, uint32_t first_hit, uint32_t n_hits, double *vis) {
+  const uint32_t hl = blockIdx.x * kBlock + threadIdx.x;
+  if (hl >= n_hits) return;
+  const uint32_t h = first_hit + hl;
+  const d3 P{sl.px[h], sl.py[h], sl.pz[h]};
+  const d3 N{sl.nx[h], sl.ny[h], sl.nz[h]};
+  const uint32_t own = sl.prim[h];
+  const d3 fire = P + (N * MIPT_RAY_EPSILON) * 3.0;  // material.cpp:117
+  const double f[3] = {fire.x, fire.y, fire.z}, nn[3] = {N.x, N.y, N.z};
+  for (int li = 0; li < S.n_lights; li++) {
+    const LightRec L = load_light_uniform(S.lights + li);
+    const bool directional = L.type == MIPT_LIGHT_DIRECTIONAL;
+    double dl[3], dh[3];  // the light's box of sample points relative to the firing point (directional: the ray's far end)
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+      double lo, hi;
+      if (directional) {
+        lo = hi = f[a] - L.orientation[a] * rc.t_max;
+      } else if (L.type == MIPT_LIGHT_RECT_AREA) {
+        const double base = L.position[a] + L.v[a], du = L.u[a] * L.uL;
+        lo = base + fmin(0.0, du) + fmin(0.0, L.vL);
+        hi = base + fmax(0.0, du) + fmax(0.0, L.vL);
+      } else {
+        lo = hi = L.position[a];
+      }
+      const double grow = 1e-9 * (S.radius + 1.0 + fabs(lo) + fabs(hi));  // far more than the rounding of a sample point
+      dl[a] = (lo - grow) - f[a];
+      dh[a] = (hi + grow) - f[a];
+    }
+    // Do all rays of the pair leave the surface the hit lies on (N.dir > 1e-6 for every sample point)?  Then a
+    // convex primitive — sphere, box or square — cannot block the rays that start 3e-8 above it, by a margin far
+    // beyond the rounding of its test: the pair skips the primitive its hit lies on, whose box the shaft always
+    // meets (the hits on a floor square would otherwise set up all their rays here to learn nothing).
+    double least = 0.0, far2 = 0.0;
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+      least += fmin(nn[a] * dl[a], nn[a] * dh[a]);
+      far2 += fmax(dl[a] * dl[a], dh[a] * dh[a]);
+    }
+    const bool leaving = least > 1e-6 * sqrt(far2);
+    for (int k = 0; k < S.n_analytic; k++) {
+      if (leaving && own == (uint32_t)k) continue;
+      const double *b = S.object_boxes + 6u * (S.prim_info[k] & 0x3fffffffu);
+      // first without a division: on some axis the box lies beside everything between the firing point and the light
+      bool apart = false;
+#pragma unroll
+      for (int a = 0; a < 3; a++) apart = apart || b[3 + a] - f[a] < fmin(0.0, dl[a]) || b[a] - f[a] > fmax(0.0, dh[a]);
+      if (apart) continue;
+      // some t in [0, 1] with F + t dl <= b.hi and F + t dh >= b.lo on every axis: two half-lines in t per axis
+      double t0 = 0.0, t1 = 1.0;
+      bool ok = true;
+#pragma unroll
+      for (int a = 0; a < 3; a++) {
+        const double up = b[3 + a] - f[a], dn = b[a] - f[a];
+        if (dl[a] > 0.0) t1 = fmin(t1, up / dl[a]);
+        else if (dl[a] < 0.0) t0 = fmax(t0, up / dl[a]);
+        else ok = ok && up >= 0.0;
+        if (dh[a] > 0.0) t0 = fmax(t0, dn / dh[a]);
+        else if (dh[a] < 0.0) t1 = fmin(t1, dn / dh[a]);
+        else ok = ok && dn <= 0.0;
+      }
+      if (!(ok && t0 <= t1 * (1.0 + 1e-12) + 1e-12)) continue;
+      for (int sidx = 0; sidx < L.samples; sidx++) {
+        const ShadowSetup su = shadow_setup(rc, L, li, sidx, fire, sl.key[h]);
+        Trav T;
+        T.org = fire;
+        T.dir = su.dir;
+        T.best.t = fmin(su.lightT, rc.t_max);
+        T.best.prim = -1;
+        T.tlimit = 0.0f;
+        T.cur = MIPT_TRAV_DONE;
+        T.sp = 0;
+        if (!ray_meets_box(T.org, T.dir, T.best.t, b)) continue;
+        if (prim_test<true, LOCAL>(T, S, (uint32_t)k)) {
+          const uint64_t item = (uint64_t)hl * (uint32_t)S.rays_per_hit + (uint32_t)(L.first_ray + sidx);
+          if (S.vis_bytes) reinterpret_cast<uint8_t *>(vis)[item] = 0;
+          else vis[item] = 0.0;
+        }
+      }
+    }
   }
 }
 
@@ -1361,6 +1472,17 @@ void launch_copy_rays(RayQueue src, uint64_t src_off, RayQueue dst, uint64_t dst
   hipLaunchKernelGGL(k_copy_rays, dim3(grid_for(n)), dim3(kBlock), 0, st, src, src_off, dst, dst_off, n);
 }
 
+typedef void (*ShadowAnyKernel)(SceneDev, RenderConst, ShadeList, uint32_t, uint32_t, double *, DeviceCounters *);
+template <bool COUNT, bool LOCAL>
+static ShadowAnyKernel shadow_any_kernel2(bool vis8, bool lean) {
+  if (vis8) return lean ? k_shadow_any<COUNT, LOCAL, true, true> : k_shadow_any<COUNT, LOCAL, true, false>;
+  return lean ? k_shadow_any<COUNT, LOCAL, false, true> : k_shadow_any<COUNT, LOCAL, false, false>;
+}
+static ShadowAnyKernel shadow_any_kernel(bool count, bool local, bool vis8, bool lean) {
+  if (count) return local ? shadow_any_kernel2<true, true>(vis8, lean) : shadow_any_kernel2<true, false>(vis8, lean);
+  return local ? shadow_any_kernel2<false, true>(vis8, lean) : shadow_any_kernel2<false, false>(vis8, lean);
+}
+
 void launch_shadow_trace(const SceneDev &S, const RenderConst &rc, ShadeList sl, uint64_t first_hit, uint32_t n_hits, double *vis,
                          DeviceCounters *dc, bool count, hipStream_t st) {
   uint64_t R = (uint64_t)S.rays_per_hit;
@@ -1370,13 +1492,13 @@ void launch_shadow_trace(const SceneDev &S, const RenderConst &rc, ShadeList sl,
     auto kern = S.local_meshes ? (count ? k_shadow_walk<true, true> : k_shadow_walk<false, true>) : (count ? k_shadow_walk<true, false> : k_shadow_walk<false, false>);
     hipLaunchKernelGGL(kern, dim3(persistent_grid(rc, items)), dim3(kBlock), stack_bytes(S), st, S, rc, sl, first_hit * R, items, vis, dc);
   } else {
-    auto kern = S.local_meshes ? (count ? k_shadow_any<true, true, false> : k_shadow_any<false, true, false>)
-                               : (count ? k_shadow_any<true, false, false> : k_shadow_any<false, false, false>);
-    if (S.vis_bytes)
-      kern = S.local_meshes ? (count ? k_shadow_any<true, true, true> : k_shadow_any<false, true, true>)
-                            : (count ? k_shadow_any<true, false, true> : k_shadow_any<false, false, true>);
+    const bool lean = S.lean_any != 0 && S.n_analytic <= kLeanAnalyticMax;
+    auto kern = shadow_any_kernel(count, S.local_meshes != 0, S.vis_bytes != 0, lean);
     (void)hipMemsetAsync(dc->dyn_next, 0, sizeof(dc->dyn_next), st);
     hipLaunchKernelGGL(kern, dim3(persistent_grid(rc, items)), dim3(kBlock), stack_bytes(S), st, S, rc, sl, (uint32_t)first_hit, items, vis, dc);
+    if (lean && S.n_analytic > 0)  // what the analytic primitives block, which the walk passed over
+      hipLaunchKernelGGL(S.local_meshes ? k_shadow_analytic<true> : k_shadow_analytic<false>, dim3(grid_for(n_hits)), dim3(kBlock), 0, st, S, rc, sl,
+                         (uint32_t)first_hit, n_hits, vis);
   }
 }
 

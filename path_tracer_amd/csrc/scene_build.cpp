@@ -955,6 +955,17 @@ int build_host_scene(const mipt_scene_desc *d, HostScene *out, std::string *err,
   if (nPrims)
     for (int a = 0; a < 3; a++) R = std::max(R, std::max(std::fabs(rootBox.mn[a]), std::fabs(rootBox.mx[a])));
   S.radius = R;
+  // world boxes of the objects, a little too large: a ray that an analytic primitive's test accepts passes
+  // through its box (the shadow kernel tests the few analytic primitives of a mesh scene ray by ray, box first)
+  S.object_boxes.resize(6 * nObj);
+  {
+    const double grow = 1e-9 * (R + 1.0);
+    for (size_t k = 0; k < nObj; k++)
+      for (int a = 0; a < 3; a++) {
+        S.object_boxes[6 * k + a] = objBoxes[6 * k + a] - grow;
+        S.object_boxes[6 * k + 3 + a] = objBoxes[6 * k + 3 + a] + grow;
+      }
+  }
 
   if (d->cubemap) {
     S.has_cubemap = true;

@@ -25,6 +25,7 @@ struct HostScene {
   std::vector<float> prim_boxes;       // flat mode only: 6 floats per primitive (min, max), rounded outward
   double bounds_min[3] = {0, 0, 0}, bounds_max[3] = {0, 0, 0};  // scene bounds
   std::vector<ObjRec> objects;
+  std::vector<double> object_boxes;    // per object: its world box (min xyz, max xyz), grown by 1e-9 of the scene's size
   std::vector<MatRec> materials;
   std::vector<LightRec> lights;
   int rays_per_hit = 0;                // shadow rays per shaded hit for a given area_samples
