@@ -493,6 +493,54 @@ def test_two_launch_streams_give_the_one_stream_frame(scenes, monkeypatch):
             assert np.abs(other - one).max() <= 1e-6, key  # float32 frames: an ulp at most
 
 
+def _mesh_scene_with_analytic_occluders(seed=11):
+    """The small benchmark layout plus a sphere, a box and a square hovering over the terrain (they cast shadows
+    and are hit themselves), beside the floor square: four analytic primitives among 20 000 triangles."""
+    from path_tracer_amd.scene import ObjectRec
+
+    sc = synth.make_scene(20000, seed=seed)
+    def place(kind, mat, pos, scale, tilt=0.0):
+        T = np.eye(4)
+        T[:3, 3] = pos
+        Sm = np.diag([scale[0], scale[1], scale[2], 1.0])
+        c, s_ = math.cos(tilt), math.sin(tilt)
+        Rx = np.array([[1, 0, 0, 0], [0, c, -s_, 0], [0, s_, c, 0], [0, 0, 0, 1.0]])
+        sc.objects.append(ObjectRec(kind, mat, -1, T @ Rx @ Sm))
+    place(abi.OBJ_SPHERE, 5, [-3.0, 2.5, -22.0], [1.6, 1.2, 1.6])
+    place(abi.OBJ_BOX, 9, [3.5, 1.5, -26.0], [2.5, 1.0, 2.0], tilt=0.4)
+    place(abi.OBJ_SQUARE, 2, [0.5, 4.0, -30.0], [6.0, 6.0, 1.0], tilt=-1.3)
+    return sc
+
+
+def test_analytic_primitives_beside_meshes_block_shadow_rays(oracle_lib, monkeypatch):
+    """In a mesh scene with a few analytic primitives the shadow walk passes those over and a pass per hit
+    (shaft of the hit's rays against the primitive's box, then the rays themselves) clears what they block;
+    MIPT_LEAN_ANY=0 keeps their tests in the walk.  Both must give the oracle's frame, shadows of the
+    analytic primitives on the meshes, on each other and on themselves included."""
+    from path_tracer_amd.raytracer import Context
+
+    sc = _mesh_scene_with_analytic_occluders()
+    orc = oracle_lib.Oracle(sc)
+    frames = []
+    for knob in ("1", "0"):
+        monkeypatch.setenv("MIPT_LEAN_ANY", knob)
+        ctx = Context(0)
+        try:
+            ctx.upload_scene(sc)
+            p = abi.default_params(160, 90, spp=1, rr_q=0.0, max_depth=3, flags=abi.FLAG_FIXED_AREA_PATTERN)
+            f32, rgb8 = ctx.render(p)
+            ref, ref8 = orc.render(p, threads=8, want_rgb8=True)
+            assert_images_match(f32, ref, rgb8, ref8)
+            p = abi.default_params(128, 72, spp=3, seed=9)
+            f32, rgb8 = ctx.render(p)
+            ref, ref8 = orc.render(p, threads=8, want_rgb8=True)
+            assert_images_match(f32, ref, rgb8, ref8)
+            frames.append(f32.astype(np.float64))
+        finally:
+            ctx.close()
+    assert np.abs(frames[0] - frames[1]).max() <= 1e-6
+
+
 def test_one_byte_visibility_records_give_the_fp64_records_frame(scenes, monkeypatch):
     # Where every light's per-sample attenuation is a constant of the light (area lights with b = c = 0, light.cpp:139-142)
     # a shadow ray's record can be one byte, the sums putting the constant in (the default in scenes of more than 4096
