@@ -27,6 +27,10 @@ constexpr int kBlock = 256;
 #ifndef MIPT_TRAV_WAVES
 #define MIPT_TRAV_WAVES 4  // waves per SIMD the traversal kernels are compiled for
 #endif
+#ifndef MIPT_LEAN_WAVES
+#define MIPT_LEAN_WAVES MIPT_TRAV_WAVES  // the same for the shadow kernel without the analytic tests (it needs fewer registers)
+#endif
+constexpr int kMaxTravWaves = MIPT_LEAN_WAVES > MIPT_TRAV_WAVES ? MIPT_LEAN_WAVES : MIPT_TRAV_WAVES;
 
 // ------------------------------------------------------------------ helpers ----
 __device__ __forceinline__ uint32_t lane_id() { return __lane_id(); }
@@ -695,7 +699,7 @@ __device__ __forceinline__ int light_of_ray(const SceneDev &S, uint32_t r) {
 // (registers), whose one analytic primitive hardly any shadow ray meets.
 constexpr int kLeanAnalyticMax = 8;
 template <bool COUNT, bool LOCAL, bool VIS8, bool LEAN>  // VIS8: one-byte records (a kernel of its own: the fp64 one keeps its code and registers)
-__global__ void __launch_bounds__(kBlock, MIPT_TRAV_WAVES) k_shadow_any(SceneDev S, RenderConst rc, ShadeList sl, uint32_t first_hit, uint32_t n_items,
+__global__ void __launch_bounds__(kBlock, (LEAN ? MIPT_LEAN_WAVES : MIPT_TRAV_WAVES)) k_shadow_any(SceneDev S, RenderConst rc, ShadeList sl, uint32_t first_hit, uint32_t n_items,
                                                                          double *__restrict__ vis, DeviceCounters *dc) {
   extern __shared__ uint32_t lds_stack[];
   const Stack stack{lds_stack + threadIdx.x, kBlock, blockIdx.x * kBlock + threadIdx.x};
@@ -1405,7 +1409,7 @@ static inline size_t stack_bytes(const SceneDev &S) { return (size_t)S.stack_ent
 int traversal_blocks_per_cu(const SceneDev &S) {
   size_t per_block = stack_bytes(S) + 256;  // + the kernels' small static LDS
   int by_lds = (int)((160u * 1024u) / per_block);
-  int n = MIPT_TRAV_WAVES < by_lds ? MIPT_TRAV_WAVES : by_lds;
+  int n = kMaxTravWaves < by_lds ? kMaxTravWaves : by_lds;  // the most any of the traversal kernels keeps resident (sizes the stack overflow area)
   return n < 1 ? 1 : n;
 }
 
@@ -1424,9 +1428,11 @@ void launch_generate(const SceneDev &S, const RenderConst &rc, const int *rows, 
 
 // Grid of a persistent traversal kernel: enough blocks to fill every CU at the compiled
 // occupancy, fewer when there is less work than that.
-static inline unsigned persistent_grid(const RenderConst &rc, uint64_t n) {
+// `waves`: the waves per SIMD (= blocks per CU) the kernel to launch is compiled for.
+static inline unsigned persistent_grid(const SceneDev &S, const RenderConst &rc, uint64_t n, int waves = MIPT_TRAV_WAVES) {
   uint64_t full = (n + kBlock - 1) / kBlock;
-  uint64_t cap = (uint64_t)rc.persist_blocks;
+  const int per_cu_max = traversal_blocks_per_cu(S);  // rc.persist_blocks = CUs x this (the most any traversal kernel keeps resident)
+  uint64_t cap = (uint64_t)rc.persist_blocks / (uint64_t)per_cu_max * (uint64_t)(waves < per_cu_max ? waves : per_cu_max);
   return (unsigned)(full < cap ? full : cap);
 }
 
@@ -1441,7 +1447,7 @@ void launch_intersect(const SceneDev &S, const RenderConst &rc, RayQueue q, uint
     kern = S.local_meshes ? (count ? k_intersect<true, true, true> : k_intersect<false, true, true>)
                           : (count ? k_intersect<true, false, true> : k_intersect<false, false, true>);
   (void)hipMemsetAsync(dc->dyn_next, 0, sizeof(dc->dyn_next), st);
-  hipLaunchKernelGGL(kern, dim3(persistent_grid(rc, traced)), dim3(kBlock), stack_bytes(S), st, S, rc, q, traced, dup, hit_t, hit_prim, dc,
+  hipLaunchKernelGGL(kern, dim3(persistent_grid(S, rc, traced)), dim3(kBlock), stack_bytes(S), st, S, rc, q, traced, dup, hit_t, hit_prim, dc,
                      cam ? *cam : CameraRays{nullptr, 0, 0, 0, 1});
 }
 
@@ -1490,12 +1496,13 @@ void launch_shadow_trace(const SceneDev &S, const RenderConst &rc, ShadeList sl,
   uint32_t items = (uint32_t)(n_hits * R);
   if (S.translucent) {
     auto kern = S.local_meshes ? (count ? k_shadow_walk<true, true> : k_shadow_walk<false, true>) : (count ? k_shadow_walk<true, false> : k_shadow_walk<false, false>);
-    hipLaunchKernelGGL(kern, dim3(persistent_grid(rc, items)), dim3(kBlock), stack_bytes(S), st, S, rc, sl, first_hit * R, items, vis, dc);
+    hipLaunchKernelGGL(kern, dim3(persistent_grid(S, rc, items)), dim3(kBlock), stack_bytes(S), st, S, rc, sl, first_hit * R, items, vis, dc);
   } else {
     const bool lean = S.lean_any != 0 && S.n_analytic <= kLeanAnalyticMax;
     auto kern = shadow_any_kernel(count, S.local_meshes != 0, S.vis_bytes != 0, lean);
     (void)hipMemsetAsync(dc->dyn_next, 0, sizeof(dc->dyn_next), st);
-    hipLaunchKernelGGL(kern, dim3(persistent_grid(rc, items)), dim3(kBlock), stack_bytes(S), st, S, rc, sl, (uint32_t)first_hit, items, vis, dc);
+    hipLaunchKernelGGL(kern, dim3(persistent_grid(S, rc, items, lean ? MIPT_LEAN_WAVES : MIPT_TRAV_WAVES)), dim3(kBlock), stack_bytes(S), st, S, rc, sl,
+                       (uint32_t)first_hit, items, vis, dc);
     if (lean && S.n_analytic > 0)  // what the analytic primitives block, which the walk passed over
       hipLaunchKernelGGL(S.local_meshes ? k_shadow_analytic<true> : k_shadow_analytic<false>, dim3(grid_for(n_hits)), dim3(kBlock), 0, st, S, rc, sl,
                          (uint32_t)first_hit, n_hits, vis);
