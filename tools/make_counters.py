@@ -33,10 +33,15 @@ KEY = {"k_intersect": "intersect", "k_shadow_any": "shadow", "k_shadow_walk": "s
        "k_shadow_sum_lights": "shadow_sum", "k_shadow_sum_tiled": "shadow_sum", "k_shadow_sum_bytes": "shadow_sum", "k_generate": "generate", "k_resolve": "resolve"}
 
 
+LEAN_SHADOW = set()  # filled by kernel_of: the shadow kernel without the analytic tests (6 waves per SIMD) was among the launches
+
+
 def kernel_of(name):
     m = re.search(r"(k_[a-z_]+)(<([^>]*)>)?", name)
     if not m:
         return None
+    if m.group(1) == "k_shadow_any" and m.group(3) and [a.strip() for a in m.group(3).split(",")][3:4] == ["true"]:
+        LEAN_SHADOW.add(True)
     if m.group(3) and m.group(3).split(",")[0].strip() == "true" and m.group(1) in ("k_intersect", "k_shadow_any", "k_shadow_walk", "k_shade"):
         return None  # the instrumented (counting) instantiation is not the timed one
     return m.group(1)
@@ -97,7 +102,7 @@ def main():
             e["valu_busy"] = val("SQ_ACTIVE_INST_VALU") * 4 / (cyc("sq1", "SQ_ACTIVE_INST_VALU") * SIMDS)
             e["lane_utilisation"] = val("SQ_THREAD_CYCLES_VALU") / (64 * val("SQ_ACTIVE_INST_VALU"))
             e["waves_per_simd"] = val("SQ_WAVE_CYCLES") * 4 / (cyc("sq1", "SQ_WAVE_CYCLES") * SIMDS)
-            e["waves_per_simd_compiled"] = 5
+            e["waves_per_simd_compiled"] = 6 if (k == "k_shadow_any" and LEAN_SHADOW) else 5  # csrc/Makefile: MIPT_TRAV_WAVES, MIPT_LEAN_WAVES
             e["kernel_ms_in_counter_pass"] = ms["sq1"].get(KEY.get(k, ""))
         if "SQ_WAIT_ANY" in c and "SQ_WAVE_CYCLES" in c:
             e["wave_time_waiting_on_memory"] = val("SQ_WAIT_ANY") / val("SQ_WAVE_CYCLES")
