@@ -346,11 +346,11 @@ __device__ __forceinline__ void node_test(const Trav &T, const SceneDev &S, int 
 // LOCAL: the scene has a mesh with ObjRec::local_units set (SceneDev::local_meshes), so a triangle
 // test looks its object up; scenes without one run kernels compiled without that path.
 // TRI_ONLY: `s` is known to be a triangle (the analytic tests are not compiled in).
-template <bool ANY, bool LOCAL, bool TRI_ONLY = false>
+template <bool ANY, bool LOCAL, bool TRI_ONLY = false, bool NO_TRI = false>  // NO_TRI: the scene has no triangles (their test is not compiled in)
 __device__ __forceinline__ bool prim_test(Trav &T, const SceneDev &S, uint32_t s) {
   double t;
   bool hit;
-  if (TRI_ONLY || s >= (uint32_t)S.n_analytic) {
+  if (TRI_ONLY || (!NO_TRI && s >= (uint32_t)S.n_analytic)) {
     double w1, w2;
     if (LOCAL) {
       const ObjRec *o = S.objects + (S.prim_info[s] & 0x3fffffffu);
@@ -381,7 +381,7 @@ __device__ __forceinline__ bool prim_test(Trav &T, const SceneDev &S, uint32_t s
 // children are entered in slot order (the builder puts large boxes first) and the first
 // primitive with t < tmax ends the walk.
 // TRI_ONLY: the leaves' analytic primitives are passed over (the caller has tested them).
-template <bool ANY, bool COUNT, bool LOCAL, bool TRI_ONLY = false>
+template <bool ANY, bool COUNT, bool LOCAL, bool TRI_ONLY = false, bool NO_TRI = false>
 __device__ __forceinline__ void trav_round(Trav &T, const SceneDev &S, const Stack &stk, TravCounters &tc) {
   int cur = T.cur, sp = T.sp;
   while (cur >= 0) {
@@ -439,7 +439,7 @@ __device__ __forceinline__ void trav_round(Trav &T, const SceneDev &S, const Sta
 #else
       if (COUNT) tc.prims++;
 #endif
-      if (prim_test<ANY, LOCAL, TRI_ONLY>(T, S, first + k) && ANY) { found = true; break; }
+      if (prim_test<ANY, LOCAL, TRI_ONLY, NO_TRI>(T, S, first + k) && ANY) { found = true; break; }
     }
     if (found || sp == 0) cur = MIPT_TRAV_DONE;
     else cur = (int)stack_pop(S, stk, sp);

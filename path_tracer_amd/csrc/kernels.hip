@@ -698,7 +698,9 @@ __device__ __forceinline__ int light_of_ray(const SceneDev &S, uint32_t r) {
 // sphere, box and square tests compiled into it, anywhere, this kernel is 7 % slower on the benchmark scene
 // (registers), whose one analytic primitive hardly any shadow ray meets.
 constexpr int kLeanAnalyticMax = 8;
-template <bool COUNT, bool LOCAL, bool VIS8, bool LEAN>  // VIS8: one-byte records (a kernel of its own: the fp64 one keeps its code and registers)
+// NO_TRI: the scene has no triangle at all (the reference's demo scenes): the triangle test and the own-triangle
+// shortcut are not compiled in either (28 B less scratch per lane: spheres.json 674 -> 702 Msamples/s).
+template <bool COUNT, bool LOCAL, bool VIS8, bool LEAN, bool NO_TRI = false>  // VIS8: one-byte records (a kernel of its own: the fp64 one keeps its code and registers)
 __global__ void __launch_bounds__(kBlock, (LEAN ? MIPT_LEAN_WAVES : MIPT_TRAV_WAVES)) k_shadow_any(SceneDev S, RenderConst rc, ShadeList sl, uint32_t first_hit, uint32_t n_items,
                                                                          double *__restrict__ vis, DeviceCounters *dc) {
   extern __shared__ uint32_t lds_stack[];
@@ -747,7 +749,7 @@ __global__ void __launch_bounds__(kBlock, (LEAN ? MIPT_LEAN_WAVES : MIPT_TRAV_WA
           // (a hit near an edge, a smooth normal on the other side) walks as usual.  Hits on
           // analytic primitives walk: their test costs more than the short walks of the small
           // scenes they make up (spheres.json 665 -> 634 Msamples/s with it, 661 without).
-          if (dot(N, su.dir) < 0.0 && sl.prim[h] >= (uint32_t)S.n_analytic) {
+          if (!NO_TRI && dot(N, su.dir) < 0.0 && sl.prim[h] >= (uint32_t)S.n_analytic) {
             if (COUNT) tc.prims++;
             if (prim_test<true, LOCAL, true>(T, S, sl.prim[h])) {
               if (VIS8) reinterpret_cast<uint8_t *>(vis)[item] = 0;
@@ -767,7 +769,7 @@ __global__ void __launch_bounds__(kBlock, (LEAN ? MIPT_LEAN_WAVES : MIPT_TRAV_WA
     if (__ballot(!idle) == 0ull) break;
     const uint32_t want_idle = exhausted ? 64u : kRefillIdle;
     do {
-      trav_round<true, COUNT, LOCAL, LEAN>(T, S, stack, tc);
+      trav_round<true, COUNT, LOCAL, LEAN, NO_TRI>(T, S, stack, tc);
       if (!idle && T.cur == MIPT_TRAV_DONE) {
         if (VIS8) reinterpret_cast<uint8_t *>(vis)[item] = T.best.prim >= 0 ? 0 : 1;
         else vis[item] = T.best.prim >= 0 ? 0.0 : scale;
@@ -1484,7 +1486,11 @@ static ShadowAnyKernel shadow_any_kernel2(bool vis8, bool lean) {
   if (vis8) return lean ? k_shadow_any<COUNT, LOCAL, true, true> : k_shadow_any<COUNT, LOCAL, true, false>;
   return lean ? k_shadow_any<COUNT, LOCAL, false, true> : k_shadow_any<COUNT, LOCAL, false, false>;
 }
-static ShadowAnyKernel shadow_any_kernel(bool count, bool local, bool vis8, bool lean) {
+static ShadowAnyKernel shadow_any_kernel(bool count, bool local, bool vis8, bool lean, bool no_tri) {
+  if (no_tri && !local && !lean) {
+    if (count) return vis8 ? k_shadow_any<true, false, true, false, true> : k_shadow_any<true, false, false, false, true>;
+    return vis8 ? k_shadow_any<false, false, true, false, true> : k_shadow_any<false, false, false, false, true>;
+  }
   if (count) return local ? shadow_any_kernel2<true, true>(vis8, lean) : shadow_any_kernel2<true, false>(vis8, lean);
   return local ? shadow_any_kernel2<false, true>(vis8, lean) : shadow_any_kernel2<false, false>(vis8, lean);
 }
@@ -1499,7 +1505,7 @@ void launch_shadow_trace(const SceneDev &S, const RenderConst &rc, ShadeList sl,
     hipLaunchKernelGGL(kern, dim3(persistent_grid(S, rc, items)), dim3(kBlock), stack_bytes(S), st, S, rc, sl, first_hit * R, items, vis, dc);
   } else {
     const bool lean = S.lean_any != 0 && S.n_analytic <= kLeanAnalyticMax;
-    auto kern = shadow_any_kernel(count, S.local_meshes != 0, S.vis_bytes != 0, lean);
+    auto kern = shadow_any_kernel(count, S.local_meshes != 0, S.vis_bytes != 0, lean, S.n_analytic == S.n_prims);
     (void)hipMemsetAsync(dc->dyn_next, 0, sizeof(dc->dyn_next), st);
     hipLaunchKernelGGL(kern, dim3(persistent_grid(S, rc, items, lean ? MIPT_LEAN_WAVES : MIPT_TRAV_WAVES)), dim3(kBlock), stack_bytes(S), st, S, rc, sl,
                        (uint32_t)first_hit, items, vis, dc);
