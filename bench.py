@@ -9,7 +9,8 @@ with scene, queues and the radiance sum resident in HBM.  Metric: path samples/s
 (one path sample = one `trace(x, y)` call of the reference, RayTracer.cpp:38-56:
 a camera ray plus its whole tree of bounce, mirror and shadow rays).
 
-With N > 1 (launched by torch.distributed.run, one rank per GPU) the SAME job is split N
+With N > 1 (one rank per GPU: launched by torch.distributed.run, or by bench.py itself when it is
+started without a launcher) the SAME job is split N
 ways (strong scaling: a step is the same S samples of every pixel whatever N is; every
 rank renders S / N of them for the whole frame, or with --sharding tiles all S for its own
 bands of rows) and the per-pixel sums are brought to rank 0 over RCCL once, inside the
@@ -153,7 +154,29 @@ def main():
     ap.add_argument("--max-depth", type=int, default=0, help="0 = the library's default (64)")
     ap.add_argument("--no-profile-events", action="store_true",
                     help="time the steps without the per-kernel HIP events (then no kernel_ms_per_step and no roofline)")
+    ap.add_argument("--rendezvous-only", action="store_true",
+                    help="launcher check that needs no GPU: the ranks meet over gloo and rank 0 prints the line's envelope (no render)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # Started by itself with N > 1: the split into ranks lives inside the call, as the reference's split into
+        # threads lives inside traceImage (RayTracer.cpp:482-489).  The ranks are children of this process, started
+        # before anything here has touched the GPU; rank 0's line goes to this process's stdout.
+        raise SystemExit(launch_ranks(args.gpus))
+
+    if args.rendezvous_only:
+        import torch.distributed as dist
+
+        world = int(os.environ.get("WORLD_SIZE", "1"))
+        if world > 1:
+            dist.init_process_group(backend="gloo")
+            dist.barrier()
+        if int(os.environ.get("RANK", "0")) == 0:
+            print(json.dumps({"metric": "path samples/s", "value": None, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,
+                              "warmup": args.warmup, "rendezvous_only": True}), flush=True)
+        if world > 1:
+            dist.destroy_process_group()
+        return
 
     import torch
     import torch.distributed as dist
@@ -166,7 +189,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus} (WORLD_SIZE={world})")
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started {world} rank(s): use --nproc-per-node {args.gpus}, or start bench.py by itself")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the render path has no CPU fallback")
     if args.backend == "gloo":
@@ -353,6 +376,30 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def launch_ranks(n):
+    """Runs this script as n ranks of one node (torch.distributed.run, one process per GPU, rendezvous on
+    127.0.0.1 at a free port) with the same arguments, and returns the launcher's exit status."""
+    import socket
+    import subprocess
+
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    # the ranks' stdout is passed on line by line: rank 0's JSON line to stdout, anything else (gloo announces its
+    # connections on stdout) to stderr, so that stdout carries the one line and nothing else
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, bufsize=1)
+    for line in proc.stdout:
+        dst = sys.stdout if line.lstrip().startswith("{") else sys.stderr
+        dst.write(line)
+        dst.flush()
+    return proc.wait()
 
 
 def kernel_source_hash():

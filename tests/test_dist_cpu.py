@@ -70,3 +70,34 @@ def test_shard_plans_partition_the_work():
         assert spans[0][0] == 0 and spans[-1][1] == 10 and all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
     with pytest.raises(ValueError):
         shard_params(base, 2, 2, "tiles")
+
+
+def test_bench_starts_its_own_ranks():
+    """`bench.py --gpus 2` started by itself (no launcher, WORLD_SIZE unset) runs two ranks that meet, and its
+    stdout is exactly one JSON line that says n_gpus = 2; --rendezvous-only stops before any GPU work."""
+    import json
+    import subprocess
+
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--rendezvous-only"],
+                         cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = res.stdout.splitlines()
+    assert len(lines) == 1, res.stdout
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["steps"] == 4 and j["warmup"] == 2
+
+
+def test_bench_passes_a_failing_rank_on():
+    """A rank that fails makes the self-launched bench fail too (here: no GPU in this container)."""
+    import subprocess
+
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("needs a machine without a GPU")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--workload", "spheres"],
+                         cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert res.returncode != 0
+    assert res.stdout.strip() == ""

@@ -50,6 +50,27 @@ __global__ void __launch_bounds__(256, 6) gather_w(const float4 *__restrict__ no
   out[tid] = acc + (float)idx;
 }
 
+// The shadow kernel's sharing pattern: runs of G adjacent lanes (the samples of one area light from one
+// hit) follow the same chain, every lane loading all NL x 16 bytes of the 64-byte record itself.
+template <int NL, int G>
+__global__ void __launch_bounds__(256, 6) gather_runs(const float4 *__restrict__ nodes, uint32_t mask, int steps, float *out) {
+  uint32_t tid = blockIdx.x * 256 + threadIdx.x;
+  uint32_t idx = (tid / G) * 2654435761u + 12345u;
+  float acc = 0.f;
+  for (int s = 0; s < steps; s++) {
+    const float4 *p = nodes + (size_t)(idx & mask) * 4;
+    float4 a = p[0];
+    acc += a.x;
+    uint32_t dep = __float_as_uint(a.w);
+    if (NL > 1) { float4 b = p[1]; acc += b.y; dep += __float_as_uint(b.w); }
+    if (NL > 2) { float4 c = p[2]; acc += c.z; dep += __float_as_uint(c.w); }
+    if (NL > 3) { float4 d = p[3]; acc += d.x; dep += __float_as_uint(d.w); }
+    idx = idx * 1664525u + 1013904223u + dep;
+    idx ^= idx >> 15;
+  }
+  out[tid] = acc + (float)idx;
+}
+
 // Cooperative form: the four lanes of a quad follow one chain and each loads its own 16-byte
 // quarter of the 64-byte record (NCH chains per quad and step = NCH loads per lane).
 template <int NCH>
@@ -146,6 +167,9 @@ int main() {
 #define RUNW(W, G) printf("  one %2d-byte load, %3d lanes per address (negative: strided over the wave): %6.1f cycles per wave-step per CU\n", W, G, \
     time_cycles([&](int st) { hipLaunchKernelGGL((gather_w<W, G>), dim3(grid), dim3(256), 0, 0, d, mask, st, out); }, 2000, mhz));
   RUNW(16, 1) RUNW(8, 1) RUNW(4, 1) RUNW(16, 2) RUNW(16, 4) RUNW(16, 16) RUNW(16, 64) RUNW(16, -2) RUNW(16, -4) RUNW(16, -16)
+#define RUNR(NL, G) printf("  %d x16B loads of a 64-byte record, runs of %2d adjacent lanes per record: %6.1f cycles per wave-step per CU\n", NL, G, \
+    time_cycles([&](int st) { hipLaunchKernelGGL((gather_runs<NL, G>), dim3(grid), dim3(256), 0, 0, d, mask, st, out); }, 2000, mhz));
+  RUNR(4, 1) RUNR(4, 2) RUNR(4, 4) RUNR(4, 10) RUNR(4, 16) RUNR(4, 64) RUNR(1, 10)
 #define RUNQ(NCH) printf("  quad-cooperative fetch of %d records per quad and step (64 B each, 16 B per lane): %6.1f cycles per wave-step per CU\n", NCH, \
     time_cycles([&](int st) { hipLaunchKernelGGL((gather_quad<NCH>), dim3(grid), dim3(256), 0, 0, d, mask, st, out); }, 2000, mhz));
   RUNQ(1) RUNQ(4)
