@@ -186,7 +186,7 @@ __device__ __forceinline__ bool tri_hit(const Tri *tr, d3 org, d3 dir, double &t
 // (node_test), 2^-21 of it, plus the rounding of off itself to fp32 (to nearest: |off| <=
 // (R + |o|) |1/d| (1 + 2^-20), so it moves by less than the 2^-23 share; a conversion with
 // directed rounding is twelve instructions on this chip, to nearest it is one).
-// Axis-parallel rays use |d| = 2^-100 R.
+// Axis-parallel rays use |d| = 1e-30.
 struct Cull {
   float idx, idy, idz;
   float nx, ny, nz;  // near-plane offsets
@@ -194,11 +194,7 @@ struct Cull {
 };
 
 __device__ __forceinline__ void cull_axis(double o, double d, double R, float &id, float &offN, float &offF) {
-  // |1/d| is kept below 2^100 / R: a step of the node frames is below R / 32, so step * 2^24 / d stays a finite
-  // float (node_test_words), and the pad, 6e-7 (R + |o|) |1/d|, is then still >= 7e23 in t: a slab that holds the
-  // origin (to within the pad's share of space) spans every t the walk asks about, whatever the cap did to 1/d
-  const double dmin = 7.888609052210118e-31 * fmax(R, 1e-6);  // 2^-100 R
-  double dd = fabs(d) < dmin ? copysign(dmin, d) : d;
+  double dd = fabs(d) < 1e-30 ? copysign(1e-30, d) : d;
   // 1/dd to ~1e-15 (the hardware estimate is good to 2^-26, one Newton step squares that): it only feeds the fp32 culling
   double inv = __builtin_amdgcn_rcp(dd);
   inv = fma(fma(-dd, inv, 1.0), inv, inv);
@@ -295,24 +291,6 @@ __device__ __forceinline__ void trav_init(Trav &T, const SceneDev &S, d3 org, d3
 
 __device__ __forceinline__ float ubyte_f(uint32_t w, int k) { return (float)((w >> (8 * k)) & 0xffu); }  // v_cvt_f32_ubyteK
 
-// Plane bytes as fp16 operands.  A 16-bit word whose high byte is zero is, read as fp16, the subnormal q * 2^-24:
-// exact and linear in the byte q.  v_fma_mix_f32 takes such a half as an fma source and widens it on the way in, so
-// a plane costs one instruction (the fma) instead of two (byte -> float, fma), after two byte permutes per word of
-// four bytes that spread its bytes over the halves of two words; the factor 2^24 goes into the other factor.
-// (A wave64 fp32 instruction issues every 4 cycles per SIMD on this chip, a permute about every 2: the node test's
-// 24 conversions were a quarter of its issue time.)
-#ifndef MIPT_NODE_MIX
-#define MIPT_NODE_MIX 0
-#endif
-__device__ __forceinline__ uint32_t halves01(uint32_t w) { return __builtin_amdgcn_perm(w, w, 0x0c010c00u); }  // {0, byte 1, 0, byte 0}
-__device__ __forceinline__ uint32_t halves23(uint32_t w) { return __builtin_amdgcn_perm(w, w, 0x0c030c02u); }  // {0, byte 3, 0, byte 2}
-template <int HALF>
-__device__ __forceinline__ float fma_half(uint32_t h, float a, float b) {  // (fp16 half HALF of h) * a + b, one rounding
-  typedef _Float16 Half2 __attribute__((ext_vector_type(2)));
-  const Half2 hv = __builtin_bit_cast(Half2, h);
-  return __builtin_fmaf((float)(HALF == 0 ? hv.x : hv.y), a, b);  // the widening folds into v_fma_mix_f32 (fp16 subnormals are kept)
-}
-
 // The descend loop of a round is left when fewer lanes than this are still in it.
 #ifndef MIPT_MIN_DESC_CLOSEST
 #define MIPT_MIN_DESC_CLOSEST 16
@@ -337,13 +315,11 @@ __device__ __forceinline__ float fma_half(uint32_t h, float a, float b) {  // (f
 // 1 % the quantised root box may stick out), so near and far values can be compared as they are.
 // node_test_words: the arithmetic on a node's four 16-byte words (also what tools/micro/valu_issue.hip times
 // on register-resident words); node_test: the fetch in front of it.
-template <bool NEED_T, bool MIX = (MIPT_NODE_MIX != 0)>
+template <bool NEED_T>
 __device__ __forceinline__ void node_test_words(const Trav &T, uint4 q0, uint4 q1, uint4 q2, int4 q3, int ch[4], float t[4], bool hit[4]) {
-  // MIX: the step times 2^24 (see fma_half): finite, make_cull keeps |1/d| below 2^100 / R and a step is below R / 32
-  const uint32_t ebias = MIX ? (24u << 23) : 0u;
-  const float ax = __uint_as_float(((q0.w & 0xffu) << 23) + ebias) * T.c.idx;
-  const float ay = __uint_as_float((((q0.w >> 8) & 0xffu) << 23) + ebias) * T.c.idy;
-  const float az = __uint_as_float((((q0.w >> 16) & 0xffu) << 23) + ebias) * T.c.idz;
+  const float ax = __uint_as_float((q0.w & 0xffu) << 23) * T.c.idx;
+  const float ay = __uint_as_float(((q0.w >> 8) & 0xffu) << 23) * T.c.idy;
+  const float az = __uint_as_float(((q0.w >> 16) & 0xffu) << 23) * T.c.idz;
   const float ox = __uint_as_float(q0.x), oy = __uint_as_float(q0.y), oz = __uint_as_float(q0.z);
   const float bnx = __fmaf_rn(ox, T.c.idx, T.c.nx), bfx = __fmaf_rn(ox, T.c.idx, T.c.fx);
   const float bny = __fmaf_rn(oy, T.c.idy, T.c.ny), bfy = __fmaf_rn(oy, T.c.idy, T.c.fy);
@@ -353,23 +329,6 @@ __device__ __forceinline__ void node_test_words(const Trav &T, uint4 q0, uint4 q
   const uint32_t nY = T.c.idy < 0.0f ? q2.x : q1.y, fY = T.c.idy < 0.0f ? q1.y : q2.x;
   const uint32_t nZ = T.c.idz < 0.0f ? q2.y : q1.z, fZ = T.c.idz < 0.0f ? q1.z : q2.y;
   ch[0] = q3.x; ch[1] = q3.y; ch[2] = q3.z; ch[3] = q3.w;
-  if constexpr (MIX) {
-  const uint32_t nXa = halves01(nX), nXb = halves23(nX), fXa = halves01(fX), fXb = halves23(fX);
-  const uint32_t nYa = halves01(nY), nYb = halves23(nY), fYa = halves01(fY), fYb = halves23(fY);
-  const uint32_t nZa = halves01(nZ), nZb = halves23(nZ), fZa = halves01(fZ), fZb = halves23(fZ);
-#define MIPT_CHILD(k, H, nXw, nYw, nZw, fXw, fYw, fZw)                                                                            \
-  {                                                                                                                            \
-    float tn = fmaxf(fmaxf(fma_half<H>(nXw, ax, bnx), fma_half<H>(nYw, ay, bny)), fmaxf(fma_half<H>(nZw, az, bnz), 0.0f));     \
-    float tf = fminf(fminf(fma_half<H>(fXw, ax, bfx), fma_half<H>(fYw, ay, bfy)), fminf(fma_half<H>(fZw, az, bfz), T.tlimit)); \
-    hit[k] = tn <= tf && ch[k] != kNoChild; /* tf <= tlimit is finite, so an overflowed tn misses */                           \
-    if (NEED_T) t[k] = hit[k] ? tn : 3.0e38f;                                                                                  \
-  }
-  MIPT_CHILD(0, 0, nXa, nYa, nZa, fXa, fYa, fZa)
-  MIPT_CHILD(1, 1, nXa, nYa, nZa, fXa, fYa, fZa)
-  MIPT_CHILD(2, 0, nXb, nYb, nZb, fXb, fYb, fZb)
-  MIPT_CHILD(3, 1, nXb, nYb, nZb, fXb, fYb, fZb)
-#undef MIPT_CHILD
-  } else {
 #pragma unroll
   for (int k = 0; k < 4; k++) {
     float tn = fmaxf(fmaxf(__fmaf_rn(ubyte_f(nX, k), ax, bnx), __fmaf_rn(ubyte_f(nY, k), ay, bny)),
@@ -378,7 +337,6 @@ __device__ __forceinline__ void node_test_words(const Trav &T, uint4 q0, uint4 q
                      fminf(__fmaf_rn(ubyte_f(fZ, k), az, bfz), T.tlimit));
     hit[k] = tn <= tf && ch[k] != kNoChild;  // tf <= tlimit is finite, so an overflowed tn misses
     if (NEED_T) t[k] = hit[k] ? tn : 3.0e38f;
-  }
   }
 }
 template <bool NEED_T>
