@@ -140,6 +140,7 @@ def main():
     ap.add_argument("--triangles", type=int, default=0)
     ap.add_argument("--batch-samples", type=int, default=0, help="samples per wavefront batch; 0 = one batch per step and rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true", help="with --no-cpu-baseline: skip the oracle's check of sampled rows too (tuning sweeps)")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     ap.add_argument("--cull-negligible", action="store_true",
                     help="set MIPT_FLAG_CULL_NEGLIGIBLE: skip shadow rays whose whole term is below 2^-52 (off: every shadow "
@@ -355,9 +356,11 @@ def main():
             out["roofline"] = roofline(args.workload, stats["device_bytes"], ktimes, K, cnt, step_samples)
             out["kernel_ms_per_step"] = {k: v["ms"] / K for k, v in ktimes.items()}
             out["kernel_launches_per_step"] = {k: v["launches"] / K for k, v in ktimes.items()}
-        if world == 1 and not args.no_cpu_baseline:
-            cb, p_cpu, img_cpu = cpu_baseline(scene, base, args.cpu_budget)
-            out["cpu_baseline"] = cb
+        if world == 1 and not (args.no_cpu_baseline and args.no_parity):
+            # without the baseline leg the oracle still checks a few sampled rows of the workload (a shorter run of the same routine)
+            cb, p_cpu, img_cpu = cpu_baseline(scene, base, args.cpu_budget if not args.no_cpu_baseline else min(args.cpu_budget, 4.0))
+            if not args.no_cpu_baseline:
+                out["cpu_baseline"] = cb
             # the same rows on the GPU, same random streams: parity of the bench workload itself
             p_gpu = abi.default_params(w, h, spp=1, band_rows=1, shard_count=p_cpu.shard_count, shard_index=0)
             p_gpu.max_depth = base.max_depth
@@ -370,7 +373,9 @@ def main():
                 "pixels_over_1e-5": int((np.abs(diff).max(axis=2) > 1e-5).sum()),
                 "pixels": int(diff.shape[0] * diff.shape[1]),
             }
-            out["vs_cpu_baseline"] = out["value"] / cb["value"] if cb["value"] > 0 else None
+            out["parity"]["sample"] = cb["sample"]
+            if not args.no_cpu_baseline:
+                out["vs_cpu_baseline"] = out["value"] / cb["value"] if cb["value"] > 0 else None
         print(json.dumps(out), flush=True)
     ctx.close()
     if world > 1:

@@ -323,6 +323,17 @@ int mipt_hit_material(mipt_ctx *ctx, int64_t n, const double *org, const double 
 int mipt_shadow_attenuation(mipt_ctx *ctx, const mipt_params *p, int light, int64_t n,
                             const double *fire, const uint64_t *key, double *out);
 
+/* The shadow rays of n shaded hits, ray by ray, through the kernels a render launches for them (the persistent
+ * any-hit kernel of the scene's kind and, where it runs, the pass over the analytic primitives; the walk through
+ * translucent occluders in scenes that have any), not the one-ray-per-thread loop of mipt_shadow_attenuation.
+ * Per hit k: P[3k] the hit point, N[3k] its normal (firePos = P + 3e-8 N, material.cpp:117), key[k] its random
+ * stream, prim[k] the primitive it lies on as mipt_intersect reports it.  out[3 * (k * R + r)], R = rays per hit
+ * (area_samples per area light + 1 per other light, lights in scene order): what ray r contributes before the
+ * division by the sample count (light.cpp:118-144), i.e. colour * min(1, 1/denom), or 0 where it is blocked.
+ * Test hook. */
+int mipt_shadow_rays(mipt_ctx *ctx, const mipt_params *p, int64_t n, const double *P, const double *N,
+                     const uint64_t *key, const int32_t *prim, double *out);
+
 /* Counters since the last reset (filled only by calls with MIPT_FLAG_COUNTERS). */
 int mipt_get_counters(mipt_ctx *ctx, mipt_counters *out);
 int mipt_reset_counters(mipt_ctx *ctx);

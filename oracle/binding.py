@@ -52,6 +52,8 @@ def load():
     lib.orc_hit_material.argtypes = [vp, i64, vp, vp, dbl, vp, vp, vp]
     lib.orc_shadow_attenuation.restype = C.c_int
     lib.orc_shadow_attenuation.argtypes = [vp, C.POINTER(abi.Params), C.c_int, i64, vp, vp, vp]
+    lib.orc_shadow_samples.restype = C.c_int
+    lib.orc_shadow_samples.argtypes = [vp, C.POINTER(abi.Params), C.c_int, i64, vp, vp, vp]
     lib.orc_shade_brdf.restype = C.c_int
     lib.orc_shade_brdf.argtypes = [vp, C.POINTER(abi.Params), C.c_int] + [C.POINTER(dbl)] * 5 + [C.c_uint64, C.POINTER(dbl)]
     lib.orc_object_order.restype = C.c_int
@@ -155,6 +157,17 @@ class Oracle:
         rc = self.lib.orc_shadow_attenuation(self._h, C.byref(params), light, n, fire.ctypes.data, keys.ctypes.data, out.ctypes.data)
         if rc != 0:
             raise RuntimeError(f"orc_shadow_attenuation rc={rc}")
+        return out
+
+    def shadow_samples(self, params, light, fire, keys=None, samples=None):
+        """Per shadow ray: (n, S, 3) with S = `samples` (area_samples for an area light, 1 otherwise)."""
+        fire = np.ascontiguousarray(fire, dtype=np.float64).reshape(-1, 3)
+        n = fire.shape[0]
+        keys = np.zeros(n, dtype=np.uint64) if keys is None else np.ascontiguousarray(keys, dtype=np.uint64)
+        out = np.empty((n, samples, 3), dtype=np.float64)
+        rc = self.lib.orc_shadow_samples(self._h, C.byref(params), light, n, fire.ctypes.data, keys.ctypes.data, out.ctypes.data)
+        if rc != 0:
+            raise RuntimeError(f"orc_shadow_samples rc={rc}")
         return out
 
     def shade_brdf(self, params, material, P, N, V, w, Lin, key=0):

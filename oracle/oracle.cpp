@@ -721,6 +721,19 @@ struct orc_scene {
     V3 finalLight(0, 0, 0);
     int S = prm.area_samples;
     for (int s = 0; s < S; s++) {
+      V3 light = areaSample(li, s, r, p, prm, rng, key, c);
+      finalLight += light;
+    }
+    finalLight /= (double)S;  // the reference divides by the literal 10 == its sample count
+    return finalLight;
+  }
+
+  // One pass of the loop of RectangleAreaLight::shadowAttenuation (light.cpp:118-144): sample s of area light li.
+  V3 areaSample(int li, int s, const Ray &r, V3 p, const mipt_params &prm, const Rng &rng, uint64_t key, Counters &c) const {
+    const Light &L = lights[li];
+    const double tmax = prm.t_max;
+    const int S = prm.area_samples;
+    {
       double uI, vI;
       if (prm.flags & MIPT_FLAG_FIXED_AREA_PATTERN) {
         uI = L.uL * ((s + 0.5) / S);
@@ -741,10 +754,8 @@ struct orc_scene {
       double d = distance(position, r.p);
       double denom = L.a + L.b * d + L.c * std::pow(d, 2);
       light *= std::min(1.0, 1 / denom);
-      finalLight += light;
+      return light;
     }
-    finalLight /= (double)S;  // the reference divides by the literal 10 == its sample count
-    return finalLight;
   }
 
   // ---- BRDF -----------------------------------------------------------------
@@ -1242,6 +1253,27 @@ int orc_shadow_attenuation(orc_scene *s, const mipt_params *p, int light, int64_
     r.d = s->lightDirection(s->lights[light], firePos);
     V3 res = s->shadowAttenuation(light, r, firePos, *p, rng, key ? key[k] : 0, c);
     out[3 * k] = res.x; out[3 * k + 1] = res.y; out[3 * k + 2] = res.z;
+  }
+  return MIPT_OK;
+}
+
+int orc_shadow_samples(orc_scene *s, const mipt_params *p, int light, int64_t n, const double *fire, const uint64_t *key, double *out) {
+  if (!s || !check_params(p) || light < 0 || light >= (int)s->lights.size()) return MIPT_ERR_INVALID;
+  uint64_t seq = 0;
+  Rng rng{ORC_RNG_COUNTER, &seq};
+  Counters c;
+  const bool area = s->lights[light].type == MIPT_LIGHT_RECT_AREA;
+  const int S = area ? p->area_samples : 1;
+  for (int64_t k = 0; k < n; k++) {
+    V3 firePos(fire[3 * k], fire[3 * k + 1], fire[3 * k + 2]);
+    Ray r;
+    r.p = firePos;
+    r.d = s->lightDirection(s->lights[light], firePos);
+    for (int sm = 0; sm < S; sm++) {
+      V3 res = area ? s->areaSample(light, sm, r, firePos, *p, rng, key ? key[k] : 0, c) : s->shadowAttenuation(light, r, firePos, *p, rng, key ? key[k] : 0, c);
+      double *o = out + 3 * ((size_t)k * S + sm);
+      o[0] = res.x; o[1] = res.y; o[2] = res.z;
+    }
   }
   return MIPT_OK;
 }

@@ -71,6 +71,12 @@ int orc_intersect_brute(orc_scene *s, int64_t n, const double *org, const double
 int orc_shadow_attenuation(orc_scene *s, const mipt_params *p, int light, int64_t n,
                            const double *fire, const uint64_t *key, double *out);
 
+/* The same per shadow ray: out[3 * (k * S + s)] is what sample s contributes before the division by the sample
+ * count (one pass of the loop of light.cpp:118-144), S = area_samples for a rectangle area light; S = 1 and the
+ * whole value for point and directional lights. */
+int orc_shadow_samples(orc_scene *s, const mipt_params *p, int light, int64_t n,
+                       const double *fire, const uint64_t *key, double *out);
+
 /* Material::shadeBRDF (material.cpp:88-170) for one hit with the lights of the
  * scene: P (hit point), N, V (= wOut direction), w (= -wIn direction, the bounce
  * direction), Lin (indirect radiance), material index, random key. */

@@ -195,6 +195,7 @@ SIGNATURES = {
     "mipt_hit_material": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mipt_intersect": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mipt_shadow_attenuation": (C.c_int, [C.c_void_p, C.POINTER(Params), C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mipt_shadow_rays": (C.c_int, [C.c_void_p, C.POINTER(Params), C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mipt_get_counters": (C.c_int, [C.c_void_p, C.POINTER(Counters)]),
     "mipt_reset_counters": (C.c_int, [C.c_void_p]),
     "mipt_get_kernel_times": (C.c_int, [C.c_void_p, C.POINTER(KernelTimes)]),

@@ -3,11 +3,14 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -71,7 +74,9 @@ struct mipt_ctx {
   int64_t scene_bytes = 0;
   int64_t n_prims = 0, n_nodes = 0;
   std::vector<LightRec> lights_host;
-  int lights_area_samples = -1;
+  int lights_area_samples = -1;  // area_samples the light records (host copy and device table) are laid out for
+  int table_area_samples = -1;   // area_samples the ray -> light table in `ray_light` is built for
+  uint64_t scene_serial = 0;     // distinguishes this context's uploads (the static workspace's table remembers whose it holds)
 
   // render workspace
   uint32_t capacity = 0;
@@ -303,31 +308,57 @@ RenderConst make_const(const mipt_ctx *c, const mipt_params *p, uint32_t capacit
   return rc;
 }
 
-// The per-hit shadow-ray block depends on area_samples: re-upload the light table
-// when it changes.
-int sync_lights(mipt_ctx *c, int area_samples) {
-  if (c->lights_area_samples == area_samples) return MIPT_OK;
-  int first = 0;
-  for (LightRec &L : c->lights_host) {
-    L.samples = (L.type == MIPT_LIGHT_RECT_AREA) ? area_samples : 1;
-    L.first_ray = first;
-    first += L.samples;
+// The per-hit shadow-ray block depends on area_samples: every light's ray count and first ray.  Lays the light
+// records out for `area_samples` (host copy and device table) if they are not; returns the rays per hit.
+int layout_lights(mipt_ctx *c, int area_samples) {
+  if (c->lights_area_samples != area_samples) {
+    int first = 0;
+    for (LightRec &L : c->lights_host) {
+      L.samples = (L.type == MIPT_LIGHT_RECT_AREA) ? area_samples : 1;
+      L.first_ray = first;
+      first += L.samples;
+    }
+    c->lights_area_samples = -1;  // until the device has them
+    if (!c->lights_host.empty())
+      HIP_TRY(c, hipMemcpy(const_cast<LightRec *>(c->dev.lights), c->lights_host.data(), c->lights_host.size() * sizeof(LightRec), hipMemcpyHostToDevice));
+    c->lights_area_samples = area_samples;
   }
-  c->dev.rays_per_hit = first;
-  {
+  return MIPT_OK;
+}
+int rays_per_hit_for(const mipt_ctx *c, int area_samples) {
+  int64_t n = 0;
+  for (const LightRec &L : c->lights_host) n += (L.type == MIPT_LIGHT_RECT_AREA) ? area_samples : 1;
+  return n > 0x7fffffff ? 0x7fffffff : (int)n;
+}
+
+// The allocating entry points' view of the lights: records laid out, and the context's own ray -> light table.
+int sync_lights(mipt_ctx *c, int area_samples) {
+  int r = layout_lights(c, area_samples);
+  if (r != MIPT_OK) return r;
+  const int first = rays_per_hit_for(c, area_samples);
+  if (c->table_area_samples != area_samples) {
     std::vector<uint16_t> table((size_t)std::max(first, 1));
     for (size_t k = 0; k < c->lights_host.size(); k++)
       for (int s = 0; s < c->lights_host[k].samples; s++) table[(size_t)(c->lights_host[k].first_ray + s)] = (uint16_t)k;
-    int r = ensure(c, c->ray_light, table.size() * sizeof(uint16_t));
-    if (r != MIPT_OK) return r;
+    if ((r = ensure(c, c->ray_light, table.size() * sizeof(uint16_t))) != MIPT_OK) return r;
+    c->table_area_samples = -1;
     HIP_TRY(c, hipMemcpy(c->ray_light.p, table.data(), table.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
-    c->dev.ray_light = reinterpret_cast<const uint16_t *>(c->ray_light.p);
+    c->table_area_samples = area_samples;
   }
-  if (!c->lights_host.empty())
-    HIP_TRY(c, hipMemcpy(const_cast<LightRec *>(c->dev.lights), c->lights_host.data(), c->lights_host.size() * sizeof(LightRec), hipMemcpyHostToDevice));
-  c->lights_area_samples = area_samples;
+  c->dev.rays_per_hit = first;
+  c->dev.ray_light = reinterpret_cast<const uint16_t *>(c->ray_light.p);
   return MIPT_OK;
 }
+
+// Whose ray -> light table the static workspace of each GPU holds (every context on a GPU shares that array).
+struct StaticTableOwner {
+  const mipt_ctx *ctx = nullptr;
+  uint64_t scene_serial = 0;
+  int area_samples = -1;
+};
+std::mutex g_static_owner_lock;
+StaticTableOwner g_static_owner[64];
+std::atomic<uint64_t> g_scene_serial{0};
 
 }  // namespace
 
@@ -409,6 +440,11 @@ int mipt_create(mipt_ctx **out, int device) {
 
 void mipt_destroy(mipt_ctx *c) {
   if (!c) return;
+  {
+    std::lock_guard<std::mutex> lock(g_static_owner_lock);  // a later context may get this one's address
+    for (StaticTableOwner &own : g_static_owner)
+      if (own.ctx == c) own = StaticTableOwner{};
+  }
   (void)hipSetDevice(c->device);
   free_scene(c);
   release(c->queue[0]);
@@ -452,6 +488,7 @@ int mipt_upload_scene(mipt_ctx *c, const mipt_scene_desc *desc) {
   SceneDev &D = c->dev;
   std::memset(&D, 0, sizeof(D));
   int r;
+  bool gpu_fallback = false;
   if (gpu_build && H.prim_info.size() >= 3) {
     // flat arrays in reference order -> tree and leaf order on the device
     const uint32_t n = (uint32_t)H.prim_info.size();
@@ -486,38 +523,47 @@ int mipt_upload_scene(mipt_ctx *c, const mipt_scene_desc *desc) {
     if (std::getenv("MIPT_BUILD_TIMING"))
       std::fprintf(stderr, "[mipt build] %-28s %8.3f s (%d nodes, %d levels, %d clustering rounds)\n", "GPU clustering BVH",
                    std::chrono::duration<double>(std::chrono::steady_clock::now() - t_build).count(), g.n_nodes, g.levels, g.rounds);
-    if (ge != hipSuccess) {
+    if (ge == hipErrorUnknown || ge == hipErrorInvalidValue) {
+      // the clustering did not converge (box areas that overflow fp32 leave every cluster without a nearest neighbour):
+      // the host builder, which works in fp64, takes the scene instead
+      drop_staging();
+      (void)hipGetLastError();
+      gpu_fallback = true;
+    } else if (ge != hipSuccess) {
       drop_staging();
       return set_err(c, ge == hipErrorOutOfMemory ? MIPT_ERR_NOMEM : MIPT_ERR_DEVICE, "GPU BVH build: %s", hipGetErrorString(ge));
     }
-    c->scene_allocs.push_back(g.nodes);
-    c->scene_allocs.push_back(g.order);
-    c->scene_bytes += (int64_t)n * (int64_t)(sizeof(Node4) + sizeof(uint32_t));
-    D.nodes = g.nodes;
-    D.ref_order = g.order;  // the flat arrays were in reference order
-    auto gathered = [&](const void *src, uint32_t bytes) -> void * {
-      void *p = nullptr;
-      if (hipMalloc(&p, (size_t)n * bytes) != hipSuccess) return nullptr;
-      c->scene_allocs.push_back(p);
-      c->scene_bytes += (int64_t)n * bytes;
-      gpu_gather_records(p, src, g.order, n, bytes, nullptr);
-      return p;
-    };
-    D.tris = (const Tri *)gathered(s_tris, sizeof(Tri));
-    D.prim_info = (const uint32_t *)gathered(s_info, sizeof(uint32_t));
-    if (s_norm) D.tri_normals = (const TriNormals *)gathered(s_norm, sizeof(TriNormals));
-    if (s_uv) D.tri_uvs = (const TriUV *)gathered(s_uv, sizeof(TriUV));
-    if (s_col) D.tri_colors = (const TriColor *)gathered(s_col, sizeof(TriColor));
-    hipError_t se = hipDeviceSynchronize();
-    drop_staging();
-    if (!D.tris || !D.prim_info || (s_norm && !D.tri_normals) || (s_uv && !D.tri_uvs) || (s_col && !D.tri_colors)) return set_err(c, MIPT_ERR_NOMEM, "out of device memory for the scene");
-    if (se != hipSuccess) return set_err(c, MIPT_ERR_DEVICE, "GPU BVH build: %s", hipGetErrorString(se));
-    H.n_analytic = g.n_analytic;
-    H.max_depth = g.levels;
-    H.stack_need = 3 * g.levels + 1;  // at most three siblings wait per level
-    c->n_nodes = g.n_nodes;
-  } else {
-    if (gpu_build) {  // too few primitives after dropping degenerate faces: host builder
+    if (!gpu_fallback) {
+      c->scene_allocs.push_back(g.nodes);
+      c->scene_allocs.push_back(g.order);
+      c->scene_bytes += (int64_t)n * (int64_t)(sizeof(Node4) + sizeof(uint32_t));
+      D.nodes = g.nodes;
+      D.ref_order = g.order;  // the flat arrays were in reference order
+      auto gathered = [&](const void *src, uint32_t bytes) -> void * {
+        void *p = nullptr;
+        if (hipMalloc(&p, (size_t)n * bytes) != hipSuccess) return nullptr;
+        c->scene_allocs.push_back(p);
+        c->scene_bytes += (int64_t)n * bytes;
+        gpu_gather_records(p, src, g.order, n, bytes, nullptr);
+        return p;
+      };
+      D.tris = (const Tri *)gathered(s_tris, sizeof(Tri));
+      D.prim_info = (const uint32_t *)gathered(s_info, sizeof(uint32_t));
+      if (s_norm) D.tri_normals = (const TriNormals *)gathered(s_norm, sizeof(TriNormals));
+      if (s_uv) D.tri_uvs = (const TriUV *)gathered(s_uv, sizeof(TriUV));
+      if (s_col) D.tri_colors = (const TriColor *)gathered(s_col, sizeof(TriColor));
+      hipError_t se = hipDeviceSynchronize();
+      drop_staging();
+      if (!D.tris || !D.prim_info || (s_norm && !D.tri_normals) || (s_uv && !D.tri_uvs) || (s_col && !D.tri_colors)) return set_err(c, MIPT_ERR_NOMEM, "out of device memory for the scene");
+      if (se != hipSuccess) return set_err(c, MIPT_ERR_DEVICE, "GPU BVH build: %s", hipGetErrorString(se));
+      H.n_analytic = g.n_analytic;
+      H.max_depth = g.levels;
+      H.stack_need = 3 * g.levels + 1;  // at most three siblings wait per level
+      c->n_nodes = g.n_nodes;
+    }
+  }
+  if (!(gpu_build && H.prim_info.size() >= 3) || gpu_fallback) {
+    if (gpu_build) {  // too few primitives after dropping degenerate faces, or the device builder gave up: host builder
       if ((rcode = build_host_scene(desc, &H, &err, true)) != MIPT_OK) return set_err(c, rcode, "%s", err.c_str());
     }
     if ((r = upload(c, H.nodes, &D.nodes)) != MIPT_OK) return r;
@@ -627,6 +673,8 @@ int mipt_upload_scene(mipt_ctx *c, const mipt_scene_desc *desc) {
   c->fuse_rays = c->fuse_rays_env >= 0 ? (uint32_t)c->fuse_rays_env : (c->n_prims > 4096 ? (1u << 17) : 0u);
   c->lights_host = H.lights;
   c->lights_area_samples = -1;
+  c->table_area_samples = -1;
+  c->scene_serial = ++g_scene_serial;
   // drop the big host copies
   std::vector<Node4>().swap(H.nodes);
   std::vector<Tri>().swap(H.tris);
@@ -741,6 +789,33 @@ static int render_core(mipt_ctx *c, const mipt_params *p, double *d_sum, hipStre
       uint64_t spilled = 0;  // entries on the overflow stack
       const uint32_t chunk = (uint32_t)batch;  // rays per launch; children of one launch always fit a queue
       uint32_t dup = (uint32_t)ns;             // the camera rays of a pixel's samples are identical
+      // What a launch left in q[cur] (m rays) becomes the next launch's input: at most `chunk` rays stay, the excess is
+      // parked on the overflow stack (the tree is growing), and a short queue is topped up from that stack.
+      auto settle = [&](uint32_t m) -> int {
+        if (m > chunk) {
+          uint32_t excess = m - chunk;
+          if (ws.may_allocate) {
+            int rs = ensure_spill(c, spilled, excess, st);
+            if (rs != MIPT_OK) return rs;
+          } else if (spilled + excess > ws.spill_cap) {
+            return set_err(c, MIPT_ERR_LIMIT,
+                           "path tree outgrew the static workspace (%llu rays waiting, room for %llu): use mipt_render_accumulate or lower max_depth",
+                           (unsigned long long)(spilled + excess), (unsigned long long)ws.spill_cap);
+          }
+          RayQueue stack = ws.may_allocate ? carve_queue(c->spill.p, (uint32_t)c->spill_cap) : carve_queue(ws.spill, (uint32_t)ws.spill_cap);
+          launch_copy_rays(q[cur], chunk, stack, spilled, excess, st);
+          spilled += excess;
+          m = chunk;
+        } else if (m < chunk && spilled > 0) {
+          uint32_t take = (uint32_t)std::min<uint64_t>(chunk - m, spilled);
+          RayQueue stack = ws.may_allocate ? carve_queue(c->spill.p, (uint32_t)c->spill_cap) : carve_queue(ws.spill, (uint32_t)ws.spill_cap);
+          launch_copy_rays(stack, spilled - take, q[cur], m, take, st);
+          spilled -= take;
+          m += take;
+        }
+        n = m;
+        return MIPT_OK;
+      };
       while (n > 0) {
         HIP_TRY(c, hipMemsetAsync(bc, 0, sizeof(BatchCounts), st));
         if (dup == 1 && n <= c->tail_rays && spilled == 0 && !count && (uint64_t)5 * n + 2048 <= cap) {  // the launch hands back < 5 n + 2048 rays
@@ -755,8 +830,10 @@ static int render_core(mipt_ctx *c, const mipt_params *p, double *d_sum, hipStre
           HIP_TRY(c, hipStreamSynchronize(st));
           if (ht.overflow || ht.next_rays > cap)
             return set_err(c, MIPT_ERR_DEVICE, "internal error: ray queue overflow in the tail launch (%u rays, capacity %u)", ht.next_rays, cap);
-          n = ht.next_rays;
           cur ^= 1;
+          // a launch of n rays can hand back close to 5 n of them (every wave its stack and its lanes' rays): more than one
+          // launch takes when n is near the entry limit, so the excess is parked like any other level's
+          if ((r = settle(ht.next_rays)) != MIPT_OK) return r;
           continue;
         }
         // where this level's shaded hits go: the whole list, or (two streams, few enough rays) one half of it
@@ -826,30 +903,8 @@ static int render_core(mipt_ctx *c, const mipt_params *p, double *d_sum, hipStre
           reading[side] = true;
         }
         HIP_TRY(c, hipGetLastError());
-        uint32_t m = h.next_rays;
         cur ^= 1;
-        if (m > chunk) {
-          // the tree is growing: park the excess on the overflow stack
-          uint32_t excess = m - chunk;
-          if (ws.may_allocate) {
-            if ((r = ensure_spill(c, spilled, excess, st)) != MIPT_OK) return r;
-          } else if (spilled + excess > ws.spill_cap) {
-            return set_err(c, MIPT_ERR_LIMIT,
-                           "path tree outgrew the static workspace (%llu rays waiting, room for %llu): use mipt_render_accumulate or lower max_depth",
-                           (unsigned long long)(spilled + excess), (unsigned long long)ws.spill_cap);
-          }
-          RayQueue stack = ws.may_allocate ? carve_queue(c->spill.p, (uint32_t)c->spill_cap) : carve_queue(ws.spill, (uint32_t)ws.spill_cap);
-          launch_copy_rays(q[cur], chunk, stack, spilled, excess, st);
-          spilled += excess;
-          m = chunk;
-        } else if (m < chunk && spilled > 0) {
-          uint32_t take = (uint32_t)std::min<uint64_t>(chunk - m, spilled);
-          RayQueue stack = ws.may_allocate ? carve_queue(c->spill.p, (uint32_t)c->spill_cap) : carve_queue(ws.spill, (uint32_t)ws.spill_cap);
-          launch_copy_rays(stack, spilled - take, q[cur], m, take, st);
-          spilled -= take;
-          m += take;
-        }
-        n = m;
+        if ((r = settle(h.next_rays)) != MIPT_OK) return r;
       }
       if (overlap) {  // the batch's last shadow sums land before its samples are resolved
         for (int k = 0; k < 2; k++)
@@ -947,38 +1002,41 @@ int mipt_render_accumulate_static(mipt_ctx *c, const mipt_params *p, double *d_s
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   unsigned char *base = static_cast<unsigned char *>(c->static_ws);
 
-  // the per-hit shadow-ray block for this area_samples: light records in place, the ray -> light
-  // table into the workspace (the allocating path keeps its own table and is told to rebuild it)
-  int first = 0;
-  for (LightRec &L : c->lights_host) {
-    L.samples = (L.type == MIPT_LIGHT_RECT_AREA) ? p->area_samples : 1;
-    L.first_ray = first;
-    first += L.samples;
-  }
+  // the per-hit shadow-ray block for this area_samples: counted first (nothing is touched when it is beyond the
+  // limits), then the light records are laid out and the ray -> light table goes into the workspace, unless this
+  // context's table for this scene and area_samples is what the workspace of this GPU already holds
+  const int first = rays_per_hit_for(c, p->area_samples);
   const uint64_t per_ray = c->dev.translucent ? 3 : 1;
   if ((uint32_t)first > kStaticMaxRaysPerHit || (uint64_t)std::max(first, 1) * per_ray > kStaticVisDoubles)
     return set_err(c, MIPT_ERR_LIMIT, "%d shadow rays per hit beyond the static workspace's limit of %u", first,
                    (unsigned)std::min<uint64_t>(kStaticMaxRaysPerHit, kStaticVisDoubles / per_ray));
-  c->lights_area_samples = -1;
-  c->dev.rays_per_hit = first;
+  if (c->device < 0 || c->device >= 64) return set_err(c, MIPT_ERR_LIMIT, "the static workspace serves devices 0..63");
+  if ((r = layout_lights(c, p->area_samples)) != MIPT_OK) return r;
+  uint16_t *d_table = reinterpret_cast<uint16_t *>(base + kOffRayLight);
   {
-    uint16_t table[256];  // staged through the stack in pieces: no host allocation either
-    uint16_t *d_table = reinterpret_cast<uint16_t *>(base + kOffRayLight);
-    size_t filled = 0, sent = 0;
-    for (size_t k = 0; k < c->lights_host.size(); k++)
-      for (int s2 = 0; s2 < c->lights_host[k].samples; s2++) {
-        table[filled++] = (uint16_t)k;
-        if (filled == 256) {
-          HIP_TRY(c, hipMemcpy(d_table + sent, table, filled * sizeof(uint16_t), hipMemcpyHostToDevice));
-          sent += filled;
-          filled = 0;
+    std::lock_guard<std::mutex> lock(g_static_owner_lock);
+    StaticTableOwner &own = g_static_owner[c->device];
+    if (own.ctx != c || own.scene_serial != c->scene_serial || own.area_samples != p->area_samples) {
+      own.ctx = nullptr;  // until the whole table is there
+      uint16_t table[256];  // staged through the stack in pieces: no host allocation either
+      size_t filled = 0, sent = 0;
+      for (size_t k = 0; k < c->lights_host.size(); k++)
+        for (int s2 = 0; s2 < c->lights_host[k].samples; s2++) {
+          table[filled++] = (uint16_t)k;
+          if (filled == 256) {
+            HIP_TRY(c, hipMemcpy(d_table + sent, table, filled * sizeof(uint16_t), hipMemcpyHostToDevice));
+            sent += filled;
+            filled = 0;
+          }
         }
-      }
-    if (filled) HIP_TRY(c, hipMemcpy(d_table + sent, table, filled * sizeof(uint16_t), hipMemcpyHostToDevice));
-    c->dev.ray_light = d_table;
+      if (filled) HIP_TRY(c, hipMemcpy(d_table + sent, table, filled * sizeof(uint16_t), hipMemcpyHostToDevice));
+      own.ctx = c;
+      own.scene_serial = c->scene_serial;
+      own.area_samples = p->area_samples;
+    }
   }
-  if (!c->lights_host.empty())
-    HIP_TRY(c, hipMemcpy(const_cast<LightRec *>(c->dev.lights), c->lights_host.data(), c->lights_host.size() * sizeof(LightRec), hipMemcpyHostToDevice));
+  c->dev.rays_per_hit = first;
+  c->dev.ray_light = d_table;
   c->dev.t_cap = p->t_max;
 
   int rows[kStaticMaxRows];  // on the stack: no host allocation either
@@ -1173,6 +1231,73 @@ int mipt_shadow_attenuation(mipt_ctx *c, const mipt_params *p, int light, int64_
   if (e == hipSuccess) e = hipMemcpy(out, d_o, v3, hipMemcpyDeviceToHost);
   (void)hipFree(d_f); (void)hipFree(d_o); (void)hipFree(d_k);
   if (e != hipSuccess) return set_err(c, MIPT_ERR_DEVICE, "mipt_shadow_attenuation: %s", hipGetErrorString(e));
+  return MIPT_OK;
+}
+
+int mipt_shadow_rays(mipt_ctx *c, const mipt_params *p, int64_t n, const double *P, const double *N, const uint64_t *key, const int32_t *prim,
+                     double *out) {
+  if (!c) return set_err(nullptr, MIPT_ERR_INVALID, "null context");
+  if (!c->have_scene) return set_err(c, MIPT_ERR_NOSCENE, "no scene uploaded");
+  int r = check_params(c, p);
+  if (r != MIPT_OK) return r;
+  if (n < 0 || (n > 0 && (!P || !N || !key || !prim || !out))) return set_err(c, MIPT_ERR_INVALID, "bad arguments");
+  if (n == 0 || c->dev.n_lights == 0) return MIPT_OK;
+  HIP_TRY(c, hipSetDevice(c->device));
+  if ((r = sync_lights(c, p->area_samples)) != MIPT_OK) return r;
+  c->dev.t_cap = p->t_max;
+  const uint64_t R = (uint64_t)c->dev.rays_per_hit;
+  if ((uint64_t)n * R > 0x7fffff00ull || n > (1 << 24)) return set_err(c, MIPT_ERR_LIMIT, "more than 2^31 shadow rays in one call");
+  // storage index of every primitive given by its reference-order index (what mipt_intersect reports)
+  std::vector<uint32_t> ref((size_t)c->n_prims), where((size_t)c->n_prims);
+  HIP_TRY(c, hipMemcpy(ref.data(), c->dev.ref_order, ref.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  for (size_t k = 0; k < ref.size(); k++)
+    if (ref[k] < where.size()) where[ref[k]] = (uint32_t)k;
+  // the shade records, as k_shade would have listed them (W does not matter to the rays)
+  const uint32_t cap = (uint32_t)n;
+  std::vector<unsigned char> host((size_t)cap * kShadeEntryBytes + 64, 0);
+  ShadeList hs = carve_shade(host.data(), cap);
+  for (int64_t k = 0; k < n; k++) {
+    if (prim[k] < 0 || prim[k] >= c->n_prims) return set_err(c, MIPT_ERR_INVALID, "hit %lld: primitive %d out of range", (long long)k, prim[k]);
+    hs.px[k] = P[3 * k]; hs.py[k] = P[3 * k + 1]; hs.pz[k] = P[3 * k + 2];
+    hs.nx[k] = N[3 * k]; hs.ny[k] = N[3 * k + 1]; hs.nz[k] = N[3 * k + 2];
+    hs.key[k] = key[k];
+    hs.slot[k] = (uint32_t)k;
+    hs.prim[k] = where[(size_t)prim[k]];
+  }
+  const size_t per_ray = c->dev.translucent ? 3 : 1;
+  void *d_list = nullptr, *d_vis = nullptr, *d_dc = nullptr;
+  hipError_t e = hipMalloc(&d_list, host.size());
+  if (e == hipSuccess) e = hipMalloc(&d_vis, (size_t)n * R * per_ray * sizeof(double));
+  if (e == hipSuccess) e = hipMalloc(&d_dc, sizeof(DeviceCounters));
+  if (e == hipSuccess) e = hipMemset(d_dc, 0, sizeof(DeviceCounters));
+  if (e == hipSuccess) e = hipMemset(d_vis, 0xff, (size_t)n * R * per_ray * sizeof(double));  // a ray the launch forgets reads as NaN / 255
+  if (e == hipSuccess) e = hipMemcpy(d_list, host.data(), host.size(), hipMemcpyHostToDevice);
+  std::vector<double> vis;
+  if (e == hipSuccess) {
+    RenderConst rc = make_const(c, p, cap, cap);
+    launch_shadow_trace(c->dev, rc, carve_shade(d_list, cap), 0, (uint32_t)n, reinterpret_cast<double *>(d_vis), reinterpret_cast<DeviceCounters *>(d_dc), false, nullptr);
+    e = hipDeviceSynchronize();
+  }
+  if (e == hipSuccess) {
+    vis.resize((size_t)n * R * per_ray);
+    e = hipMemcpy(vis.data(), d_vis, vis.size() * sizeof(double), hipMemcpyDeviceToHost);
+  }
+  (void)hipFree(d_list); (void)hipFree(d_vis); (void)hipFree(d_dc);
+  if (e != hipSuccess) return set_err(c, MIPT_ERR_DEVICE, "mipt_shadow_rays: %s", hipGetErrorString(e));
+  const uint8_t *vis8 = reinterpret_cast<const uint8_t *>(vis.data());
+  for (int64_t k = 0; k < n; k++)
+    for (const LightRec &L : c->lights_host)
+      for (int sm = 0; sm < L.samples; sm++) {
+        const size_t ray = (size_t)k * R + (size_t)(L.first_ray + sm);
+        double *o = out + 3 * ray;
+        if (c->dev.translucent) {
+          for (int a = 0; a < 3; a++) o[a] = vis[3 * ray + a];
+        } else {
+          // one-byte records say "reached its light": the light's constant scale goes in as the sum kernels put it in
+          const double v = c->dev.vis_bytes ? (vis8[ray] == 1 ? L.flat_scale : vis8[ray] == 0 ? 0.0 : std::nan("")) : vis[ray];
+          for (int a = 0; a < 3; a++) o[a] = L.color[a] * v;
+        }
+      }
   return MIPT_OK;
 }
 

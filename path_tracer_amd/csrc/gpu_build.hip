@@ -291,6 +291,7 @@ void gpu_gather_records(void *dst, const void *src, const uint32_t *order, uint3
 hipError_t gpu_build_bvh(const float *d_boxes, const uint32_t *d_prim_info, uint32_t n, const double bmin[3], const double bmax[3], int leaf_max,
                          GpuBvh *out, hipStream_t st) {
   *out = GpuBvh();
+  if (n < 2) return hipErrorInvalidValue;  // a single primitive has no tree: its "root" would be a leaf without children
   hipError_t e = hipSuccess;
   std::vector<void *> tmp;
   auto alloc = [&](size_t bytes) -> void * {
@@ -353,7 +354,7 @@ hipError_t gpu_build_bvh(const float *d_boxes, const uint32_t *d_prim_info, uint
     if (made == 0) {
       // nothing paired: what is left is one cluster of analytic primitives and one of triangles
       // (clusters of one kind always hold a mutual pair); the root joins them, analytic side first
-      if (kept != 2) { e = hipErrorUnknown; break; }
+      if (kept != 2) { e = hipErrorUnknown; break; }  // no mutual pair among > 2 clusters (non-finite box areas): the caller falls back
       int two[2];
       e = hipMemcpy(two, cl[cur], 8, hipMemcpyDeviceToHost);
       if (e != hipSuccess) break;

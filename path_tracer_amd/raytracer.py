@@ -109,6 +109,17 @@ class Context:
         self._check(self.lib.mipt_shadow_attenuation(self._h, C.byref(params), light, n, fire.ctypes.data, keys.ctypes.data, out.ctypes.data))
         return out
 
+    def shadow_rays(self, params: abi.Params, P, N, keys, prims, rays_per_hit: int):
+        """Ray-by-ray results of the render's own shadow kernels for the given shaded hits: (n, rays_per_hit, 3)."""
+        P = np.ascontiguousarray(P, dtype=np.float64).reshape(-1, 3)
+        N = np.ascontiguousarray(N, dtype=np.float64).reshape(-1, 3)
+        n = P.shape[0]
+        keys = np.ascontiguousarray(keys, dtype=np.uint64)
+        prims = np.ascontiguousarray(prims, dtype=np.int32)
+        out = np.full((n, rays_per_hit, 3), np.nan, dtype=np.float64)
+        self._check(self.lib.mipt_shadow_rays(self._h, C.byref(params), n, P.ctypes.data, N.ctypes.data, keys.ctypes.data, prims.ctypes.data, out.ctypes.data))
+        return out
+
     def counters(self) -> dict:
         c = abi.Counters()
         self._check(self.lib.mipt_get_counters(self._h, C.byref(c)))

@@ -112,3 +112,34 @@ def test_config4_full_scene_rows_against_the_oracle(gpu, oracle_lib):
     assert (diff <= 1e-5).mean() >= 0.998, f"{(diff > 1e-5).sum()} of {diff.size} pixels differ (max {diff.max():.3e})"
     other = np.setdiff1d(np.arange(h), rows)
     assert f32[other].sum() == 0                                        # rows outside the shard stay 0 (traceSetup zero-fills)
+
+
+def test_config5_at_ten_million_triangles_against_the_oracle(gpu, oracle_lib):
+    """Config 5 at its own triangle count: 10 M triangles (a 2 GB tree, eight times the Infinity Cache, the deepest
+    traversal stacks), 64 area lights + the directional one, the cubemap, 3840 x 2160.  20 000 closest hits ray by
+    ray, then three rows of the frame at 1 spp (641 shadow rays per shaded hit) against the oracle."""
+    sc = config5_scene(10_000_000)
+    assert sc.n_triangles() > 9_900_000 and len(sc.lights) == 65
+    orc = oracle_lib.Oracle(sc)
+    upload(gpu, sc)
+    assert gpu.scene_stats()["device_bytes"] > 1_500_000_000
+    org, d = U.camera_rays(sc, 20000, seed=77)
+    t, prim, n = orc.intersect(org, d)
+    tg, pg, ng = gpu.intersect(org, d)
+    hit = prim >= 0
+    assert 0.3 < hit.mean() < 1.0
+    same = pg == prim
+    assert same.mean() >= 0.9995, f"{(~same).sum()} of {len(same)} rays end on another primitive"
+    ok = same & hit
+    assert np.abs(tg[ok] - t[ok]).max() <= 1e-9 and np.abs(ng[ok] - n[ok]).max() <= 1e-9
+    w, h = 3840, 2160
+    p = abi.default_params(w, h, spp=1, band_rows=1, shard_count=720, shard_index=300)   # rows 300, 1020, 1740
+    f32, _ = gpu.render(p, want_rgb8=False)
+    ref, cnt = orc.render(p, threads=16, want_counters=True)
+    assert cnt["shadow_rays"] == 641 * cnt["shaded_hits"] and cnt["shaded_hits"] > 5000
+    rows = np.array([300, 1020, 1740])
+    assert np.abs(ref[rows]).mean() > 0.02
+    diff = np.abs(f32[rows].astype(np.float64) - ref[rows]).max(axis=2)
+    assert (diff <= 1e-5).mean() >= 0.998, f"{(diff > 1e-5).sum()} of {diff.size} pixels differ (max {diff.max():.3e})"
+    other = np.setdiff1d(np.arange(h), rows)
+    assert f32[other].sum() == 0

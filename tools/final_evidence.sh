@@ -1,8 +1,8 @@
 set -e
 mkdir -p gpurun_out/final
-bash tools/profile_round.sh gpurun_out/prof_1m r02 synth1m > gpurun_out/prof_1m.log 2>&1
+bash tools/profile_round.sh gpurun_out/prof_1m r03 synth1m > gpurun_out/prof_1m.log 2>&1
 cp gpurun_out/prof_1m/counters.json profiles/counters.json
-bash tools/profile_round.sh gpurun_out/prof_10m r02 synth10m --spp-per-step 8 --steps 2 > gpurun_out/prof_10m.log 2>&1
+bash tools/profile_round.sh gpurun_out/prof_10m r03 synth10m --spp-per-step 8 --steps 2 > gpurun_out/prof_10m.log 2>&1
 cp gpurun_out/prof_10m/counters.json profiles/counters.json
 cp profiles/counters.json gpurun_out/final/counters.json
 timeout -k 10 300 python bench.py --steps 20 --warmup 5 > gpurun_out/final/bench_synth1m.json 2> gpurun_out/final/bench_synth1m.err

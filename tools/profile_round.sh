@@ -8,9 +8,9 @@
 OUT=$1; TAG=$2; WL=$3; shift 3
 export TMPDIR=/tmp
 mkdir -p "$OUT"
-timeout -s KILL 500 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 bench.py --workload "$WL" --no-cpu-baseline "$@" > "$OUT/stats_bench.json" 2> "$OUT/stats.err" || { echo "stats pass failed"; tail -5 "$OUT/stats.err"; exit 1; }
+timeout -s KILL 500 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 bench.py --workload "$WL" --no-cpu-baseline --no-parity "$@" > "$OUT/stats_bench.json" 2> "$OUT/stats.err" || { echo "stats pass failed"; tail -5 "$OUT/stats.err"; exit 1; }
 find "$OUT/stats" -name '*kernel_stats.csv' -exec cp {} "$OUT/kernel_stats_${TAG}_${WL}.csv" \;
-ARGS="--workload $WL --steps 1 --warmup 0 --no-cpu-baseline $*"
+ARGS="--workload $WL --steps 1 --warmup 0 --no-cpu-baseline --no-parity $*"
 pass() {
   name=$1; shift
   timeout -s KILL 500 rocprofv3 --pmc "$@" --output-format csv -d "$OUT/$name" -- python3 bench.py $ARGS > "$OUT/$name.json" 2> "$OUT/$name.err" || { echo "pass $name failed"; tail -5 "$OUT/$name.err"; exit 1; }
