@@ -194,10 +194,12 @@ typedef struct mipt_params {
   int32_t sample_begin;
   int32_t sample_end;
   int32_t batch_samples; /* path samples per wavefront batch (also the most
-                            rays one kernel launch takes); 0 = default 2^24,
-                            at most 2^28.  The workspace takes about 600 bytes
-                            of device memory per sample of a batch plus 16 per
-                            shadow ray of its widest level                    */
+                            rays one kernel launch takes), at most 2^28.  The
+                            workspace takes about 480 bytes of device memory
+                            per sample of a batch plus 8 per shadow ray of a
+                            hit.  0 = as large as the job and 60 % of the
+                            card's free memory allow (between 2^20 and 2^28):
+                            large batches are faster                          */
 } mipt_params;
 
 /* Work counters (summed over everything rendered since the last reset). */
@@ -248,6 +250,23 @@ void mipt_default_params(mipt_params *p, int width, int height);
 int mipt_create(mipt_ctx **out, int device);
 void mipt_destroy(mipt_ctx *ctx);
 
+/* Choices a caller may make about how the library works; none changes a result.  No counterpart in the
+ * reference.  They take effect at the next mipt_upload_scene.  (The library reads no environment variable
+ * unless the process sets MIPT_DEBUG=1, which opens the tuning and test knobs of the same names in upper
+ * case, MIPT_BUILDER=gpu, MIPT_LDS_STACK, ...)
+ *   "builder"      0 = BVH built on the host (binned SAH; default), 1 = on the device (clustering; tens of
+ *                  milliseconds for 10 M triangles, ~1.14x the traversal time); scenes below 4096 primitives
+ *                  always use the host builder
+ *   "leaf_max"     1..8, primitives per leaf the device builder aims for (default 2)
+ *   "lds_stack"    1..24, traversal-stack entries per lane kept in LDS (default 24; the rest lives in HBM)
+ *   "lean_any"     -1 = automatic, 0 = keep the analytic primitives' tests inside the shadow walk
+ *   "vis_bytes"    -1 = automatic, 0 = fp64 shadow-ray records, 1 = one byte wherever that is exact
+ *   "tail_rays", "fuse_rays"   -1 = automatic, else the widest tree level (rays) that the depth-first
+ *                  finishing launches take (0 = never)
+ *   "overlap_rays" widest level whose shadow rays run on the second launch stream (default 2^18)
+ * Returns MIPT_ERR_INVALID for an unknown name or a value out of range. */
+int mipt_set_option(mipt_ctx *ctx, const char *name, int64_t value);
+
 /* Hand the loaded scene to the device: replaces what RayTracer::loadScene
  * leaves behind (RayTracer.cpp:333-415): Scene::add + ComputeBoundingBox
  * (scene.cpp:54-107), Trimesh::buildTree (trimesh.cpp:62-68) and
@@ -272,9 +291,11 @@ int mipt_render(mipt_ctx *ctx, const mipt_params *p, float *rgb_f32, uint8_t *rg
  * work is enqueued and its queue sizes are known (it synchronises `stream`). */
 int mipt_render_accumulate(mipt_ctx *ctx, const mipt_params *p, double *d_sum, void *stream);
 
-/* mipt_render_accumulate for callers that cannot allocate device memory (code under HIP graph
- * capture, tight serving loops, harnesses that forbid hipMalloc).  No counterpart in the
- * reference.  Same arguments, same result in d_sum; the queues, hit records, per-sample sums and
+/* mipt_render_accumulate for callers that cannot allocate device memory (tight serving loops that
+ * must not fragment or grow the heap, harnesses that forbid hipMalloc).  No counterpart in the
+ * reference.  Like the allocating call it is synchronous: it synchronises `stream` after every tree
+ * level to read two counters back and makes small blocking host-to-device copies (light table, row
+ * list), so it cannot run under HIP graph capture.  Same arguments, same result in d_sum; the queues, hit records, per-sample sums and
  * shadow-ray results live in a static 48 MiB device array instead of buffers sized to the job
  * (one copy per GPU the library is loaded on, held until the process ends), and the call makes
  * no hipMalloc / hipFree.  Work proceeds in batches of 2^14 path samples whatever batch_samples

@@ -186,6 +186,7 @@ SIGNATURES = {
     "mipt_default_params": (None, [C.POINTER(Params), C.c_int, C.c_int]),
     "mipt_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int]),
     "mipt_destroy": (None, [C.c_void_p]),
+    "mipt_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int64]),
     "mipt_upload_scene": (C.c_int, [C.c_void_p, C.POINTER(SceneDesc)]),
     "mipt_render": (C.c_int, [C.c_void_p, C.POINTER(Params), C.c_void_p, C.c_void_p]),
     "mipt_render_accumulate": (C.c_int, [C.c_void_p, C.POINTER(Params), C.c_void_p, C.c_void_p]),

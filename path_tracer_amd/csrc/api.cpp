@@ -100,6 +100,14 @@ struct mipt_ctx {
   uint32_t fuse_rays = 0;            // mesh scenes: a level with at most this many rays is followed to the end by one launch that
   long fuse_rays_env = -1;           // exports its shaded hits to the shadow kernels (MIPT_FUSE_RAYS, or -1: chosen at upload)
   mipt_counters totals{};
+  // mipt_set_option; -1 = decided by the library (per scene at upload)
+  struct Options {
+    int builder_gpu = 0;   // "builder": 1 = the BVH is built on the device
+    int leaf_max = 2;      // "leaf_max": primitives per leaf the device builder aims for
+    int lds_stack = 24;    // "lds_stack": traversal stack entries per lane kept in LDS
+    int lean_any = -1;     // "lean_any": 0 keeps the analytic primitives' tests inside the shadow walk
+    int vis_bytes = -1;    // "vis_bytes": 0 = fp64 visibility records, 1 = one byte wherever that is exact
+  } opt;
 
   // MIPT_FLAG_PROFILE: event pairs recorded around kernel launches, resolved after
   // the stream has been synchronised
@@ -399,7 +407,7 @@ int mipt_create(mipt_ctx **out, int device) {
   if (!c) return set_err(nullptr, MIPT_ERR_NOMEM, "out of host memory");
   c->device = device;
   std::memset(&c->dev, 0, sizeof(c->dev));
-  if (const char *e = std::getenv("MIPT_TAIL_RAYS")) {  // tuning knob
+  if (const char *e = debug_env("MIPT_TAIL_RAYS")) {  // tuning knob (MIPT_DEBUG=1 only, like the others)
     long v = std::atol(e);
     if (v >= 0 && v <= (1l << 24)) c->tail_rays_env = v;
   }
@@ -417,12 +425,12 @@ int mipt_create(mipt_ctx **out, int device) {
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
     c->n_cus = prop.multiProcessorCount;
-  if (const char *e = std::getenv("MIPT_OVERLAP")) c->overlap = std::atoi(e) != 0;  // measurement knobs
-  if (const char *e = std::getenv("MIPT_FUSE_RAYS")) {
+  if (const char *e = debug_env("MIPT_OVERLAP")) c->overlap = std::atoi(e) != 0;  // measurement knobs
+  if (const char *e = debug_env("MIPT_FUSE_RAYS")) {
     long v = std::atol(e);
     if (v >= 0 && v <= (1l << 24)) c->fuse_rays_env = v;
   }
-  if (const char *e = std::getenv("MIPT_OVERLAP_RAYS")) {
+  if (const char *e = debug_env("MIPT_OVERLAP_RAYS")) {
     long v = std::atol(e);
     if (v >= 0 && v <= (1l << 30)) c->overlap_rays = (uint32_t)v;
   }
@@ -465,6 +473,22 @@ void mipt_destroy(mipt_ctx *c) {
   delete c;
 }
 
+int mipt_set_option(mipt_ctx *c, const char *name, int64_t value) {
+  if (!c || !name) return set_err(c, MIPT_ERR_INVALID, "null argument");
+  auto in = [&](int64_t lo, int64_t hi) { return value >= lo && value <= hi; };
+  const std::string n(name);
+  if (n == "builder" && in(0, 1)) c->opt.builder_gpu = (int)value;
+  else if (n == "leaf_max" && in(1, 8)) c->opt.leaf_max = (int)value;
+  else if (n == "lds_stack" && in(1, 24)) c->opt.lds_stack = (int)value;
+  else if (n == "lean_any" && in(-1, 1)) c->opt.lean_any = (int)value;
+  else if (n == "vis_bytes" && in(-1, 1)) c->opt.vis_bytes = (int)value;
+  else if (n == "tail_rays" && in(-1, 1 << 24)) c->tail_rays_env = (long)value;
+  else if (n == "fuse_rays" && in(-1, 1 << 24)) c->fuse_rays_env = (long)value;
+  else if (n == "overlap_rays" && in(0, 1 << 30)) c->overlap_rays = (uint32_t)value;
+  else return set_err(c, MIPT_ERR_INVALID, "unknown option or value out of range: %s = %lld", name, (long long)value);
+  return MIPT_OK;
+}
+
 int mipt_upload_scene(mipt_ctx *c, const mipt_scene_desc *desc) {
   if (!c) return set_err(nullptr, MIPT_ERR_INVALID, "null context");
   HIP_TRY(c, hipSetDevice(c->device));
@@ -474,11 +498,11 @@ int mipt_upload_scene(mipt_ctx *c, const mipt_scene_desc *desc) {
   int rcode;
   // MIPT_BUILDER=gpu: build the BVH on the GPU (nearest-neighbour clustering, tens of milliseconds, ~1.15x slower to traverse)
   // instead of the host's binned SAH; small scenes always use the host builder
-  const char *bsel = std::getenv("MIPT_BUILDER");
+  const char *bsel = debug_env("MIPT_BUILDER");
   int64_t prim_guess = desc ? desc->n_objects : 0;
   if (desc && desc->meshes)
     for (int k = 0; k < desc->n_meshes; k++) prim_guess += desc->meshes[k].n_faces;
-  const bool gpu_build = bsel && std::strcmp(bsel, "gpu") == 0 && prim_guess >= 4096;
+  const bool gpu_build = (bsel ? std::strcmp(bsel, "gpu") == 0 : c->opt.builder_gpu != 0) && prim_guess >= 4096;
   try {
     rcode = build_host_scene(desc, &H, &err, !gpu_build);
   } catch (const std::bad_alloc &) {
@@ -512,15 +536,15 @@ int mipt_upload_scene(mipt_ctx *c, const mipt_scene_desc *desc) {
       drop_staging();
       return set_err(c, MIPT_ERR_NOMEM, "out of device memory while staging the scene");
     }
-    int leaf_max = 2;
-    if (const char *lm = std::getenv("MIPT_LEAF_MAX")) {
+    int leaf_max = c->opt.leaf_max;
+    if (const char *lm = debug_env("MIPT_LEAF_MAX")) {
       int v = std::atoi(lm);
       if (v >= 1 && v <= 8) leaf_max = v;
     }
     GpuBvh g;
     auto t_build = std::chrono::steady_clock::now();
     hipError_t ge = gpu_build_bvh((const float *)s_boxes, (const uint32_t *)s_info, n, H.bounds_min, H.bounds_max, leaf_max, &g, nullptr);
-    if (std::getenv("MIPT_BUILD_TIMING"))
+    if (debug_env("MIPT_BUILD_TIMING"))
       std::fprintf(stderr, "[mipt build] %-28s %8.3f s (%d nodes, %d levels, %d clustering rounds)\n", "GPU clustering BVH",
                    std::chrono::duration<double>(std::chrono::steady_clock::now() - t_build).count(), g.n_nodes, g.levels, g.rounds);
     if (ge == hipErrorUnknown || ge == hipErrorInvalidValue) {
@@ -611,15 +635,16 @@ int mipt_upload_scene(mipt_ctx *c, const mipt_scene_desc *desc) {
     if (!H.object_boxes.empty()) HIP_TRY(c, hipMemcpy(p, H.object_boxes.data(), H.object_boxes.size() * sizeof(double), hipMemcpyHostToDevice));
     D.object_boxes = reinterpret_cast<const double *>(p);
     D.lean_any = (H.n_analytic <= 8 && (size_t)H.n_analytic < H.prim_info.size()) ? 1 : 0;
-    if (const char *e = std::getenv("MIPT_LEAN_ANY")) {  // measurement knob: 0 keeps the analytic tests in the walk
+    if (c->opt.lean_any == 0) D.lean_any = 0;
+    if (const char *e = debug_env("MIPT_LEAN_ANY")) {  // measurement knob: 0 keeps the analytic tests in the walk
       if (std::atoi(e) == 0) D.lean_any = 0;
     }
   }
   // traversal stacks: up to kLdsStackMax entries per lane in LDS (6 blocks x 256 lanes x 24
   // entries fill 144 of a CU's 160 KB), the rest of the worst case in global memory
   const int kLdsStackMax = 24;
-  int lds_entries = kLdsStackMax;
-  if (const char *e = std::getenv("MIPT_LDS_STACK")) {  // test and tuning knob
+  int lds_entries = std::min(kLdsStackMax, std::max(1, c->opt.lds_stack));
+  if (const char *e = debug_env("MIPT_LDS_STACK")) {  // test and tuning knob
     int v = std::atoi(e);
     if (v >= 1 && v <= 60) lds_entries = v;
   }
@@ -647,7 +672,8 @@ int mipt_upload_scene(mipt_ctx *c, const mipt_scene_desc *desc) {
   // shadow ray's walk is so short that its byte store, which shares a word with its neighbours', costs more than the
   // sums save (cornellBoxes with an area light: shadow kernel 202 -> 211 ms, sums 26 -> 24)
   D.vis_bytes = (!H.translucent && H.flat_lights && H.prim_info.size() > 4096) ? 1 : 0;
-  if (const char *e = std::getenv("MIPT_VIS_BYTES")) {  // measurement and test knob: 0 = fp64 records, 1 = bytes wherever they are exact
+  if (c->opt.vis_bytes >= 0) D.vis_bytes = (c->opt.vis_bytes != 0 && !H.translucent && H.flat_lights) ? 1 : 0;
+  if (const char *e = debug_env("MIPT_VIS_BYTES")) {  // measurement and test knob: 0 = fp64 records, 1 = bytes wherever they are exact
     D.vis_bytes = (std::atoi(e) != 0 && !H.translucent && H.flat_lights) ? 1 : 0;
   }
   D.local_meshes = H.local_meshes ? 1 : 0;
@@ -952,7 +978,22 @@ int mipt_render_accumulate(mipt_ctx *c, const mipt_params *p, double *d_sum, voi
   ws.may_allocate = true;
   ws.spill = nullptr;
   ws.spill_cap = 0;
-  ws.batch = p->batch_samples > 0 ? p->batch_samples : (1ll << 24);
+  if (p->batch_samples > 0) {
+    ws.batch = p->batch_samples;
+  } else {
+    // As large as the job and the card allow: the deep, nearly empty levels of a path tree cost every batch the same
+    // ~15 ms, so few large batches beat many small ones (config 4: 323 Msamples/s at 2^25 samples per batch, 372 at 2^28).
+    // A sample takes two queue entries in each of the two queues and the hit records, a shade record, its sums and the
+    // results of its shadow rays; 60 % of what is free now (plus what this context already holds) goes to the workspace,
+    // the rest stays for the overflow stack of growing trees and for the caller.
+    size_t free_b = 0, total_b = 0;
+    HIP_TRY(c, hipMemGetInfo(&free_b, &total_b));
+    const size_t held = c->queue[0].bytes + c->queue[1].bytes + c->shade.bytes + c->hits.bytes + c->accum.bytes + c->vis.bytes;
+    const double per_sample = 4.0 * (double)kEntryBytes + 2.0 * (sizeof(double) + sizeof(int)) + (double)kShadeEntryBytes + 3.0 * sizeof(double) +
+                              (double)std::max(1, c->dev.rays_per_hit) * sizeof(double) * (c->dev.translucent ? 3.0 : 1.0);
+    const double fit = 0.6 * (double)(free_b + held) / per_sample;
+    ws.batch = (int64_t)std::min<double>((double)(1ll << 28), std::max<double>((double)(1 << 20), fit));
+  }
   // the batch the core will form (SB samples of PB pixels, PB*SB <= B) decides the sizes
   int64_t SB = std::min<int64_t>(ns_total, ws.batch);
   int64_t PB = std::min<int64_t>(std::max<int64_t>(1, ws.batch / SB), owned);

@@ -539,7 +539,7 @@ void reference_visit_order(const std::vector<double> &boxes, std::vector<uint32_
 namespace {
 // MIPT_BUILD_TIMING=1 prints the time of each build phase to stderr.
 struct PhaseTimer {
-  bool on = std::getenv("MIPT_BUILD_TIMING") != nullptr;
+  bool on = debug_env("MIPT_BUILD_TIMING") != nullptr;
   std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
   void lap(const char *what) {
     auto n = std::chrono::steady_clock::now();
@@ -562,7 +562,7 @@ int build_host_scene(const mipt_scene_desc *d, HostScene *out, std::string *err,
   if (d->n_objects >= (1 << 30)) return fail(MIPT_ERR_LIMIT, "too many objects (limit 2^30-1)");
 
   g_face_weight[0] = g_face_weight[1] = g_face_weight[2] = 1.0;
-  if (const char *e = std::getenv("MIPT_SAH_WEIGHTS")) {  // tuning knob: "wx,wy,wz"
+  if (const char *e = debug_env("MIPT_SAH_WEIGHTS")) {  // tuning knob: "wx,wy,wz"
     double w[3];
     if (std::sscanf(e, "%lf%*[,:]%lf%*[,:]%lf", &w[0], &w[1], &w[2]) == 3 && w[0] > 0 && w[1] > 0 && w[2] > 0)
       for (int a = 0; a < 3; a++) g_face_weight[a] = w[a];
@@ -880,7 +880,7 @@ int build_host_scene(const mipt_scene_desc *d, HostScene *out, std::string *err,
                               prims.begin());
   S.n_analytic = (int)nAnalytic;
   Builder builder(prims);
-  if (const char *lm = std::getenv("MIPT_LEAF_MAX")) {  // tuning knob: preferred primitives per leaf
+  if (const char *lm = debug_env("MIPT_LEAF_MAX")) {  // tuning knob: preferred primitives per leaf
     int v = std::atoi(lm);
     if (v >= 1 && v <= kLeafHard) builder.leaf_max = v;
   }

@@ -9,7 +9,19 @@
 #include "../../include/mipt.h"
 #include "layout.h"
 
+#include <cstdlib>
+#include <cstring>
+
 namespace mipt {
+
+// Tuning and test knobs read from the environment (MIPT_TAIL_RAYS, MIPT_LDS_STACK, ...) count only in a process
+// that sets MIPT_DEBUG=1: a library whose kernels are chosen by stray environment variables is a support hazard.
+// What a caller may want to choose is in mipt_set_option (include/mipt.h).
+inline const char *debug_env(const char *name) {
+  const char *gate = std::getenv("MIPT_DEBUG");
+  if (!gate || std::strcmp(gate, "0") == 0 || gate[0] == 0) return nullptr;
+  return std::getenv(name);
+}
 
 struct HostScene {
   CameraRec camera;

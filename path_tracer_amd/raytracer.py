@@ -50,6 +50,10 @@ class Context:
         if rc != 0:
             raise MiptError(rc, self.lib.mipt_last_error(self._h).decode())
 
+    def set_option(self, name: str, value: int):
+        """mipt_set_option: "builder", "lds_stack", ... (include/mipt.h); takes effect at the next upload."""
+        self._check(self.lib.mipt_set_option(self._h, name.encode(), int(value)))
+
     def upload_scene(self, scene: Scene):
         desc, keep = scene.to_c()
         self._check(self.lib.mipt_upload_scene(self._h, C.byref(desc)))

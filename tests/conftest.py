@@ -7,6 +7,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+# the library reads its tuning and test knobs (MIPT_LDS_STACK, MIPT_BUILDER, ...) only in a process that says so
+os.environ.setdefault("MIPT_DEBUG", "1")
+
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 SCENE_NAMES = ("spheres", "spheresDirectional", "cornellBoxes", "hitchcockBRDF", "singleSphere", "areaLight", "room", "russianRouletteTest")
 

@@ -485,6 +485,32 @@ def test_growing_path_trees_spill_to_the_overflow_stack(gpu, oracle_lib):
     assert_images_match(f32, ref)
 
 
+def test_options_choose_code_paths_not_results(gpu):
+    """mipt_set_option: the device builder, a two-entry LDS stack, fp64 shadow records and the analytic tests inside the
+    walk give the frame the defaults give (to the rounding of sums made in another order)."""
+    from path_tracer_amd.raytracer import MiptError
+
+    sc = _mesh_scene_with_analytic_occluders()
+    p = abi.default_params(80, 60, spp=3, seed=9)
+    upload(gpu, sc)
+    base = gpu.render(p, want_rgb8=False)[0].astype(np.float64)
+    assert base.mean() > 0.02
+    choices = {"builder": 1, "lds_stack": 2, "vis_bytes": 0, "lean_any": 0, "fuse_rays": 0, "overlap_rays": 0}
+    try:
+        for name, value in choices.items():
+            gpu.set_option(name, value)
+        upload(gpu, sc)
+        other = gpu.render(p, want_rgb8=False)[0].astype(np.float64)
+        assert np.abs(other - base).max() <= 1e-6
+        with pytest.raises(MiptError):
+            gpu.set_option("no_such_option", 1)
+        with pytest.raises(MiptError):
+            gpu.set_option("lds_stack", 1000)
+    finally:
+        for name, value in {"builder": 0, "lds_stack": 24, "vis_bytes": -1, "lean_any": -1, "fuse_rays": -1, "overlap_rays": 1 << 18}.items():
+            gpu.set_option(name, value)
+
+
 def test_tail_launch_output_larger_than_a_batch_is_parked(gpu, oracle_lib):
     # The launch that finishes small levels depth first hands back what its waves could not finish: close to five rays
     # per input ray when every hit spawns two (facing mirrors, no Russian roulette).  With 6300 camera rays in the last

@@ -5,6 +5,7 @@
 #      mixes) over ONE step of it, each in a profiler run of its own,
 #   3. tools/make_counters.py -> profiles/counters.json (stamped with the kernel-source hash).
 # usage: tools/profile_round.sh <outdir> <tag> <workload> [bench args...]
+export MIPT_DEBUG=1  # the library reads its tuning knobs only then
 OUT=$1; TAG=$2; WL=$3; shift 3
 export TMPDIR=/tmp
 mkdir -p "$OUT"

@@ -2,6 +2,7 @@
 # Kernel tuning: runs bench.py once per library variant under gpurun_variants/ and per
 # value of the environment knob given as KNOB=v1,v2,... (default: none).
 # usage: tools/sweep.sh [KNOB=v1,v2,...] [bench args...]
+export MIPT_DEBUG=1  # the library reads its tuning knobs only then
 knob=""; vals="-"
 if [[ "$1" == *=* ]]; then knob="${1%%=*}"; vals="${1#*=}"; shift; fi
 for lib in gpurun_variants/*.so; do
