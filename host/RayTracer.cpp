@@ -6,7 +6,7 @@
 
 namespace host {
 
-RayTracer::RayTracer(int device) {
+RayTracer::RayTracer(int device) : device_(device) {
   mipt_default_params(&params_, 0, 0);
   if (mipt_create(&ctx_, device) != MIPT_OK) {
     alert_ = mipt_last_error(nullptr);
@@ -14,7 +14,21 @@ RayTracer::RayTracer(int device) {
   }
 }
 
-RayTracer::~RayTracer() { mipt_destroy(ctx_); }
+RayTracer::~RayTracer() {
+  mipt_dist_destroy(dist_);
+  mipt_destroy(ctx_);
+}
+
+bool RayTracer::joinRanks(int rank, int n_ranks, const unsigned char id[MIPT_DIST_ID_BYTES], int mode) {
+  mipt_dist_destroy(dist_);
+  dist_ = nullptr;
+  dist_mode_ = mode;
+  if (mipt_dist_init(&dist_, rank, n_ranks, id, device_) != MIPT_OK) {
+    alert_ = mipt_dist_last_error();
+    return false;
+  }
+  return true;
+}
 
 bool RayTracer::upload() {
   if (!ctx_) return false;
@@ -79,6 +93,12 @@ void RayTracer::traceImage(int w, int h) {
   if (!loaded_) return;
   params_.sample_begin = 0;
   params_.sample_end = params_.spp;
+  if (dist_) {  // the split lives inside the call, like the reference's threads (RayTracer.cpp:482-489)
+    const bool root = mipt_dist_rank(dist_) == 0;
+    if (mipt_dist_render(dist_, ctx_, &params_, dist_mode_, root ? buffer_f32_.data() : nullptr, root ? buffer_.data() : nullptr) != MIPT_OK)
+      alert_ = mipt_dist_last_error();
+    return;
+  }
   if (mipt_render(ctx_, &params_, buffer_f32_.data(), buffer_.data()) != MIPT_OK) alert_ = mipt_last_error(ctx_);
 }
 

@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "../include/mipt.h"
+#include "../include/mipt_dist.h"
 #include "scene_loader.h"
 
 namespace host {
@@ -45,6 +46,13 @@ class RayTracer {
   // range of columns (RayTracer.cpp:482-487); the rows of other shards stay as traceSetup left them.
   void setShard(int index, int count, int band_rows = 8);
 
+  // One process per GPU, joined over RCCL: this instance becomes rank `rank` of `n_ranks` (collective: every rank
+  // calls it with the id rank 0 made with mipt_dist_new_id), and traceImage then renders this rank's share of the
+  // frame — of the sample range (MIPT_SHARD_SAMPLES) or of the bands of rows (MIPT_SHARD_TILES) — and brings the
+  // sums to rank 0 with one collective; the finished frame is in rank 0's buffer, the other ranks' stay zero.
+  bool joinRanks(int rank, int n_ranks, const unsigned char id[MIPT_DIST_ID_BYTES], int mode = MIPT_SHARD_SAMPLES);
+  int rank() const { return dist_ ? mipt_dist_rank(dist_) : 0; }
+
   // The reference's literals (N = 100, q = 0.1, 10 shadow rays, t < 1000) as settings.
   mipt_params &settings() { return params_; }
   const std::string &lastAlert() const { return alert_; }
@@ -53,6 +61,9 @@ class RayTracer {
  private:
   bool upload();
   mipt_ctx *ctx_ = nullptr;
+  int device_ = 0;
+  mipt_dist *dist_ = nullptr;
+  int dist_mode_ = MIPT_SHARD_SAMPLES;
   SceneData scene_;
   bool loaded_ = false;
   std::vector<unsigned char> buffer_;  // w*h*3, index (i + j*w)*3, j = 0 is the bottom row

@@ -104,3 +104,48 @@ def test_product_package_never_touches_the_oracle():
         for f in os.listdir(host):
             if f.endswith((".cpp", ".h")):
                 assert "oracle" not in open(os.path.join(host, f)).read(), f
+
+
+# ---- libmiptdist.so (include/mipt_dist.h): the multi-GPU render over RCCL ----------------------------------
+DIST_HEADER = os.path.join(ROOT, "include", "mipt_dist.h")
+
+
+def load_dist():
+    from path_tracer_amd import abi
+
+    abi.load_library()  # libmiptdist.so resolves libmipt.so by soname
+    return C.CDLL(os.path.join(ROOT, "path_tracer_amd", "libmiptdist.so"))
+
+
+def test_dist_library_exports_every_declared_symbol():
+    text = re.sub(r"/\*.*?\*/", "", open(DIST_HEADER).read(), flags=re.S)
+    names = sorted(set(re.findall(r"\b(mipt_dist_[a-z_0-9]+)\s*\(", text)))
+    assert {"mipt_dist_new_id", "mipt_dist_init", "mipt_dist_render", "mipt_dist_shard_params", "mipt_dist_destroy"} <= set(names)
+    lib = load_dist()
+    for name in names:
+        assert hasattr(lib, name), f"{name} is not exported by libmiptdist.so"
+
+
+def test_dist_shard_plans_partition_the_job():
+    """mipt_dist_shard_params (host arithmetic, no device): the ranks' shares are disjoint and cover the job, and they
+    are the shares path_tracer_amd.dist.shard_params gives the Python ranks."""
+    from path_tracer_amd import abi
+    from path_tracer_amd.dist import shard_params
+
+    lib = load_dist()
+    lib.mipt_dist_shard_params.restype = C.c_int
+    lib.mipt_dist_shard_params.argtypes = [C.POINTER(abi.Params), C.c_int, C.c_int, C.c_int, C.POINTER(abi.Params)]
+    base = abi.default_params(64, 37, spp=10, band_rows=4)
+    base.sample_begin, base.sample_end = 2, 9
+    for world in (1, 2, 3, 8):
+        for mode, name in ((0, "samples"), (1, "tiles")):
+            for r in range(world):
+                mine = abi.Params()
+                assert lib.mipt_dist_shard_params(C.byref(base), r, world, mode, C.byref(mine)) == 0
+                want = shard_params(base, r, world, name)
+                for field, _ in abi.Params._fields_:
+                    assert getattr(mine, field) == getattr(want, field), (world, name, r, field)
+    mine = abi.Params()
+    assert lib.mipt_dist_shard_params(C.byref(base), 2, 2, 0, C.byref(mine)) == abi.ERR_INVALID
+    sharded = abi.default_params(8, 8, shard_index=1, shard_count=2)
+    assert lib.mipt_dist_shard_params(C.byref(sharded), 0, 2, 1, C.byref(mine)) == abi.ERR_INVALID

@@ -225,3 +225,23 @@ def test_ray_cli_shards_add_up_to_the_single_gpu_frame(scene_file, tmp_path):
     r = subprocess.run([exe, "--combine", str(out), parts[0], parts[0]], capture_output=True)
     assert r.returncode == 1 and b"overlaps" in r.stderr
     assert subprocess.run([exe] + common + ["--shard", "3/3", scene_file, str(out)], capture_output=True).returncode == 1
+
+
+@pytest.mark.gpu
+def test_ray_cli_ranks_over_the_collective_library(scene_file, tmp_path):
+    """`ray --ranks N`: the program starts its own ranks, they join through libmiptdist.so (RCCL) and rank 0 writes
+    the frame.  One GPU is leased to a test, and RCCL wants a GPU per rank, so the group here has one rank (launch,
+    id hand-over, the render through mipt_dist_render and the resolve on the root all run; the collective of a group
+    of one is the identity); both shardings give the plain frame byte for byte.  Two ranks on one GPU must fail
+    cleanly, not hang."""
+    exe = os.path.join(HOST, "ray")
+    whole = tmp_path / "whole.ppm"
+    common = ["-w", "64", "-H", "44", "-s", "4"]
+    assert subprocess.run([exe] + common + [scene_file, str(whole)], capture_output=True).returncode == 0
+    for mode in ("samples", "tiles"):
+        out = tmp_path / f"ranks_{mode}.ppm"
+        r = subprocess.run([exe] + common + ["--ranks", "1", "--sharding", mode, scene_file, str(out)], capture_output=True, timeout=120)
+        assert r.returncode == 0, r.stderr.decode()
+        assert out.read_bytes() == whole.read_bytes()
+    r = subprocess.run([exe] + common + ["--ranks", "1", "--rank", "1", "--id-file", str(tmp_path / "id"), scene_file, str(whole)], capture_output=True)
+    assert r.returncode == 1 and b"--ranks" in r.stderr
