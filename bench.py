@@ -36,9 +36,18 @@ import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
 INFINITY_CACHE_BYTES = 256 << 20
-# VALU issue roof: 256 CUs x 4 SIMDs, one wave-instruction per 4 cycles and SIMD at 2.4 GHz (the
-# rate at which SQ_ACTIVE_INST_VALU reads "busy": 0.84 busy = 0.84 of this many instructions)
-VALU_PEAK_GINST = 256 * 4 * 2.4 / 4.0
+# Measured rulers of the chip (tools/micro/valu_issue.hip -> profiles/r03_valu_issue.json; tools/micro/gather_bench.hip ->
+# profiles/r03_gather_bench.txt), at the shader clock those programs read inside their kernels under load:
+N_SIMD, N_CU, SHADER_GHZ = 1024, 256, 2.39
+VALU_CYC_ISSUE = 2.2   # cycles a wave64 vector instruction holds its SIMD's issue port (v_fma_f32, v_mov_b32, v_and_b32 ... alone: 2.2-2.4)
+VALU_CYC_SLOW = 4.13   # cycles most opcodes (fp64, conversions, min/max, compares, selects ...) also hold the narrower pipe; the two overlap across waves
+VMEM_CYC_LANE_LOAD = 1.05        # cycles of a CU's vector-L1 path per 16-byte lane-load when every lane reads a 64-byte record of its own (269 per 256)
+VMEM_CYC_LANE_LOAD_RUNS10 = 0.52  # the same when runs of ten adjacent lanes read the same record (134 per 256)
+
+
+def valu_peak_ginst(cycles_per_instruction):
+    return N_SIMD * SHADER_GHZ / cycles_per_instruction
+
 
 WORKLOADS = {
     # name: (triangles, width, height, area lights, cubemap, nominal spp)
@@ -437,17 +446,17 @@ def load_counters(workload, kernel, step_samples=None):
 
 
 def roofline(workload, scene_bytes, ktimes, K, cnt, step_samples):
-    """The roof that binds the dominant kernel (the one with the most device time).
+    """The roof that binds the dominant kernel (the one with the most device time), against MEASURED peaks.
 
-    Two candidates: HBM (HBM-side bytes per launch / launch time against 8 TB/s) and vector-instruction
-    issue (VALU wave-instructions per launch / launch time against CUs x SIMDs x clock / 4); the one
-    the kernel sits closer to is reported as `bound`.  The traversal kernels gather 16-byte words
-    that the caches serve (a scene within the 256 MiB Infinity Cache never leaves the die; the 2 GB
-    scene still finds 57 % of its reads in L2), so it is the issue roof, with the vector-L1 path
-    (`tcp_busy`) saturating beside it.  Launch durations are this run's own (HIP events on
-    the launch stream around every launch of the timed steps); instruction counts and HBM-side
-    bytes per launch come from the committed counter passes of the same kernel sources over a step of
-    the same size, and are null otherwise.  The algorithmic-byte rate is always reported as
+    Three candidates.  (i) Vector-instruction issue: SQ_INSTS_VALU per launch / launch time against N_SIMD x clock /
+    cycles-per-instruction, where cycles-per-instruction = max(2.2, 4.13 x share of slow-class opcodes) is what the issue
+    micro-benchmark gives for the kernel's own instruction mix (tools/valu_mix.py, the census of its compiled loop).
+    (ii) The vector-L1 address path: the share of cycles the vector L1 (TCP) was busy (counter), beside the rate of 16-byte
+    lane-loads (four per node visit, three to six per primitive test, from this run's work counters) and what the gather
+    micro-benchmark sustains.  (iii) HBM: HBM-side bytes per launch / launch time against 8 TB/s.  The largest fraction is
+    `bound`.  Launch durations are this run's own (HIP events on the launch stream around every launch of the timed steps);
+    instruction counts, busy shares and HBM-side bytes come from the committed counter passes of the same kernel sources
+    over a step of the same size, and are null otherwise.  The algorithmic-byte rate is always reported as
     `cache_served_gbs`; it is a roofline fraction only where HBM is the bound."""
     dominant = max(("intersect", "shadow"), key=lambda k: ktimes[k]["ms"])
     name = "k_shadow_any" if dominant == "shadow" else "k_intersect"
@@ -462,6 +471,38 @@ def roofline(workload, scene_bytes, ktimes, K, cnt, step_samples):
     if pmc and abs(pmc.get("launches_per_step", launches_step) - launches_step) > 0.05 * launches_step:
         pmc = None  # another launch sequence than the one the passes averaged over
     traffic = pmc.get("hbm_bytes_per_launch") if pmc else None
+    hbm_frac = traffic / avg_launch_s / 1e9 / HBM_PEAK_GBS if traffic else None
+    # lane-loads of the walk, from this run's own work counters (per launch)
+    if dominant == "shadow":
+        nodes, prims = cnt["shadow_node_visits"], cnt["shadow_prim_tests"]
+    else:
+        nodes, prims = cnt["node_visits"] - cnt["shadow_node_visits"], cnt["prim_tests"] - cnt["shadow_prim_tests"]
+    ll_low, ll_high = (4 * nodes + 3 * prims) / max(1.0, launches_step), (4 * nodes + 6 * prims) / max(1.0, launches_step)
+    ll_rate = 0.5 * (ll_low + ll_high) / avg_launch_s / 1e9
+    vmem = {
+        "lane_loads_per_launch": [ll_low, ll_high],
+        "g_lane_loads_per_s": ll_rate,
+        "peak_every_lane_its_own_record": N_CU * SHADER_GHZ / VMEM_CYC_LANE_LOAD,
+        "peak_runs_of_ten_lanes_per_record": N_CU * SHADER_GHZ / VMEM_CYC_LANE_LOAD_RUNS10,
+        "tcp_busy": pmc.get("tcp_busy") if pmc else None,
+        "ta_busy": pmc.get("ta_busy") if pmc else None,
+        "vmem_read_instructions_per_launch": pmc.get("vmem_read_instructions_per_launch") if pmc else None,
+    }
+    inst = pmc.get("valu_instructions_per_launch") if pmc else None
+    mix = pmc.get("valu_mix") if pmc else None
+    valu_rate = inst / avg_launch_s / 1e9 if inst else None
+    cpi = mix["cycles_per_instruction"] if mix else VALU_CYC_SLOW  # without a census: every instruction counted slow-class
+    valu_frac = valu_rate / valu_peak_ginst(cpi) if valu_rate else None
+    valu = {
+        "g_wave_instructions_per_s": valu_rate,
+        "peak_for_the_kernels_mix": valu_peak_ginst(cpi),
+        "cycles_per_instruction_of_the_mix": cpi,
+        "slow_class_share": mix["slow_class_share"] if mix else None,
+        "peak_all_slow_class": valu_peak_ginst(VALU_CYC_SLOW),
+        "peak_all_fast_class": valu_peak_ginst(VALU_CYC_ISSUE),
+        "frac": valu_frac,
+        "useful_frac": valu_frac * pmc["lane_utilisation"] if valu_frac and pmc.get("lane_utilisation") else None,
+    }
     r = {
         "kernel": name,
         "avg_launch_ms": avg_launch_s * 1e3,
@@ -470,43 +511,35 @@ def roofline(workload, scene_bytes, ktimes, K, cnt, step_samples):
         "algorithmic_bytes_per_launch": alg_bytes_launch,
         "algorithmic_bytes_per_sample": (algorithmic_bytes(cnt, "intersect") + algorithmic_bytes(cnt, "shadow") + 64 * cnt["shaded_hits"]) / step_samples,
         "traffic": traffic,
-        "hbm_frac": traffic / avg_launch_s / 1e9 / HBM_PEAK_GBS if traffic else None,
-        "utilisation": {k: pmc[k] for k in ("valu_busy", "lane_utilisation", "waves_per_simd", "waves_per_simd_compiled", "ta_busy", "tcp_busy",
+        "hbm_frac": hbm_frac,
+        "valu": valu,
+        "vmem_address": vmem,
+        "utilisation": {k: pmc[k] for k in ("lane_utilisation", "waves_per_simd", "waves_per_simd_compiled", "ta_busy", "tcp_busy",
                                             "l1_miss_rate", "l2_hit_rate", "wave_time_waiting_on_memory") if k in pmc} if pmc else None,
         "counters_from": pmc.get("measured") if pmc else None,
+        "rulers": "profiles/r03_valu_issue.json, profiles/r03_gather_bench.txt (measured on MI355X at %.2f GHz in-kernel)" % SHADER_GHZ,
     }
-    inst = pmc.get("valu_instructions_per_launch") if pmc else None
-    valu_rate = inst / avg_launch_s / 1e9 if inst else None
-    valu_frac = valu_rate / VALU_PEAK_GINST if valu_rate else None
-    r["valu_frac"] = valu_frac
-    r["valu_useful_frac"] = valu_frac * pmc["lane_utilisation"] if valu_frac and pmc.get("lane_utilisation") else None
-    # which roof binds: with counters, the one the kernel sits closer to; without, HBM only for scenes beyond the Infinity Cache
-    if pmc and valu_frac is not None and r["hbm_frac"] is not None:
-        valu_bound = valu_frac >= r["hbm_frac"]
+    # which roof: the largest of the three fractions; without counters, the lane-load count against the gather rate for
+    # scenes the caches hold, HBM beyond them
+    vmem_frac = vmem["tcp_busy"] if vmem["tcp_busy"] is not None else min(1.0, ll_rate / vmem["peak_every_lane_its_own_record"])
+    cands = {"vmem_address": vmem_frac, "valu": valu_frac or 0.0, "hbm": hbm_frac if hbm_frac is not None else (cache_served / HBM_PEAK_GBS if scene_bytes > INFINITY_CACHE_BYTES and not pmc else 0.0)}
+    bound = max(cands, key=lambda k: cands[k])
+    if bound == "valu":
+        r.update({"bound": "valu", "achieved": valu_rate, "peak": valu["peak_for_the_kernels_mix"], "unit": "G wave-instructions/s", "frac": valu_frac,
+                  "note": "vector-instruction issue: SQ_INSTS_VALU per launch / this run's launch time against the measured issue rate for the kernel's "
+                          "instruction mix; the vector-L1 path (vmem_address.tcp_busy) is as close to its own roof"})
+    elif bound == "vmem_address":
+        if vmem["tcp_busy"] is not None:
+            r.update({"bound": "vmem_address", "achieved": vmem["tcp_busy"], "peak": 1.0, "unit": "share of cycles the vector L1 is busy", "frac": vmem["tcp_busy"],
+                      "note": "the vector-L1 address path: every lane gathers 16-byte words of its own node and triangle records; g_lane_loads_per_s beside the "
+                              "gather micro-benchmark's rates says the same; vector-instruction issue (valu.frac) is within a few per cent of its own roof"})
+        else:
+            r.update({"bound": "vmem_address", "achieved": ll_rate, "peak": vmem["peak_every_lane_its_own_record"], "unit": "G 16-byte lane-loads/s", "frac": vmem_frac,
+                      "note": "no counter pass for these kernel sources: lane-loads counted from the work counters (4 per node visit, 3-6 per primitive test) against "
+                              "the gather micro-benchmark's rate for lanes that share nothing; lanes that share a line make the real demand smaller"})
     else:
-        valu_bound = scene_bytes <= INFINITY_CACHE_BYTES
-    if valu_bound:
-        r.update({
-            "bound": "valu",
-            "achieved": valu_rate,
-            "peak": VALU_PEAK_GINST,
-            "unit": "G wave-instructions/s",
-            "frac": valu_frac,
-            "note": "vector-instruction issue binds, not HBM (hbm_frac = HBM-side bytes per launch / launch time / 8 TB/s): achieved = "
-                    "SQ_INSTS_VALU per launch (counter pass of these kernel sources) / this run's launch time against CUs x SIMDs x clock / 4; "
-                    "valu_useful_frac = frac x share of lanes at work; cache_served_gbs = algorithmic bytes / launch time (served by the "
-                    "caches: not a roofline fraction)",
-        })
-    else:
-        r.update({
-            "bound": "hbm",
-            "achieved": cache_served,
-            "peak": HBM_PEAK_GBS,
-            "unit": "GB/s",
-            "frac": cache_served / HBM_PEAK_GBS,
-            "note": "achieved = algorithmic bytes per launch / launch time against HBM peak; traffic = HBM-side bytes per launch "
-                    "(2 x FETCH_SIZE + WRITE_SIZE) from the counter pass of these kernel sources, hbm_frac = its share of peak",
-        })
+        r.update({"bound": "hbm", "achieved": cache_served if traffic is None else traffic / avg_launch_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                  "frac": cands["hbm"], "note": "HBM: bytes per launch / launch time against the HBM peak"})
     return r
 
 

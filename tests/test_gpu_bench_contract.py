@@ -38,7 +38,8 @@ def test_the_bench_line_has_its_fields():
     roof = j["roofline"]
     for key in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "avg_launch_ms"):
         assert key in roof, key
-    assert roof["bound"] in ("hbm", "valu") and roof["peak"] > 0 and roof["avg_launch_ms"] > 0
+    assert roof["bound"] in ("hbm", "valu", "vmem_address") and roof["peak"] > 0 and roof["avg_launch_ms"] > 0
+    assert 0 < roof["frac"] <= 1.0 and roof["vmem_address"]["g_lane_loads_per_s"] > 0 and roof["valu"]["peak_all_slow_class"] > 500
     cb = j["cpu_baseline"]
     for key in ("value", "unit", "cores", "kind", "sample"):
         assert key in cb, key

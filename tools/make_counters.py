@@ -34,6 +34,7 @@ KEY = {"k_intersect": "intersect", "k_shadow_any": "shadow", "k_shadow_walk": "s
 
 
 LEAN_SHADOW = set()  # filled by kernel_of: the shadow kernel without the analytic tests (6 waves per SIMD) was among the launches
+INSTANCES = defaultdict(lambda: defaultdict(int))  # kernel -> template arguments -> dispatches seen (which instantiation the workload runs)
 
 
 def kernel_of(name):
@@ -44,7 +45,19 @@ def kernel_of(name):
         LEAN_SHADOW.add(True)
     if m.group(3) and m.group(3).split(",")[0].strip() == "true" and m.group(1) in ("k_intersect", "k_shadow_any", "k_shadow_walk", "k_shade"):
         return None  # the instrumented (counting) instantiation is not the timed one
+    if m.group(3):
+        INSTANCES[m.group(1)][tuple(a.strip() for a in m.group(3).split(","))] += 1
     return m.group(1)
+
+
+def mangled_pattern(kernel):
+    """Regex for the assembly symbol of the instantiation of `kernel` this workload dispatched most (bool arguments only)."""
+    if not INSTANCES.get(kernel):
+        return None
+    args = max(INSTANCES[kernel].items(), key=lambda kv: kv[1])[0]
+    if not all(a in ("true", "false") for a in args):
+        return None
+    return kernel + "I" + "".join("Lb1E" if a == "true" else "Lb0E" for a in args) + "E"
 
 
 def read_pass(d):
@@ -106,6 +119,10 @@ def main():
             e["kernel_ms_in_counter_pass"] = ms["sq1"].get(KEY.get(k, ""))
         if "SQ_WAIT_ANY" in c and "SQ_WAVE_CYCLES" in c:
             e["wave_time_waiting_on_memory"] = val("SQ_WAIT_ANY") / val("SQ_WAVE_CYCLES")
+        if "SQ_INSTS_VMEM_RD" in c:
+            e["vmem_read_instructions_per_launch"] = val("SQ_INSTS_VMEM_RD") / c["SQ_INSTS_VMEM_RD"][1]
+        if "TCP_TOTAL_CACHE_ACCESSES_sum" in c:
+            e["tcp_accesses_per_launch"] = val("TCP_TOTAL_CACHE_ACCESSES_sum") / c["TCP_TOTAL_CACHE_ACCESSES_sum"][1]
         if "SQ_INSTS_SALU" in c:
             nl = c["SQ_INSTS_SALU"][1]
             e["salu_instructions_per_launch"] = val("SQ_INSTS_SALU") / nl
@@ -119,6 +136,28 @@ def main():
         if lps:
             e["launches_per_step"] = lps  # per-launch figures are averages over the launches of such a step
         kernels[k] = e
+    # issue classes of the traversal kernels' instructions (tools/valu_mix.py: static census of the instantiation this
+    # workload ran, its persistent loop): the ceiling of their vector-instruction rate depends on that mix
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import valu_mix
+
+        asm = valu_mix.compile_asm()
+        for k in ("k_shadow_any", "k_intersect"):
+            pat = mangled_pattern(k)
+            if k not in kernels or not pat:
+                continue
+            for name, lines in valu_mix.kernel_bodies(asm):
+                if pat in name:
+                    outer, inner = valu_mix.hot_loop(lines)
+                    whole = valu_mix.census(lines[outer[0]:outer[1] + 1]) if outer else valu_mix.census(lines)
+                    kernels[k]["valu_mix"] = {"instantiation": pat, "valu_in_persistent_loop": whole["valu"], "slow_class_share": whole["slow_share"],
+                                              "cycles_per_instruction": whole["cycles_per_instruction"]}
+                    if inner:
+                        dl = valu_mix.census(lines[inner[0]:inner[1] + 1])
+                        kernels[k]["valu_mix"]["descend_loop"] = {"valu": dl["valu"], "slow_class_share": dl["slow_share"], "cycles_per_instruction": dl["cycles_per_instruction"]}
+    except Exception as ex:  # no compiler on this machine: the census is optional
+        print("valu_mix skipped:", ex, file=sys.stderr)
     step = bench_json(os.path.join(d, "sq1.json")) or {}
     out = {}
     if dest and os.path.exists(dest):

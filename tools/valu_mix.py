@@ -73,14 +73,19 @@ def hot_loop(lines):
     return outer, inner
 
 
-def main():
-    pats = sys.argv[1:] or [r"k_shadow_anyILb0ELb0ELb1ELb1ELb0E", r"k_intersectILb0ELb0ELb0E", r"k_shadow_anyILb0ELb0ELb0ELb0ELb1E"]
+def compile_asm():
+    """The kernels' gfx950 assembly, compiled as csrc/Makefile compiles them."""
     src = os.path.join(ROOT, "path_tracer_amd", "csrc", "kernels.hip")
     with tempfile.TemporaryDirectory() as tmp:
         out = os.path.join(tmp, "k.s")
         subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-DMIPT_TRAV_WAVES=5", "-DMIPT_LEAN_WAVES=6",
                                "-S", "--cuda-device-only", "-o", out, src], stderr=subprocess.DEVNULL)
-        asm = open(out).read()
+        return open(out).read()
+
+
+def main():
+    pats = sys.argv[1:] or [r"k_shadow_anyILb0ELb0ELb1ELb1ELb0E", r"k_intersectILb0ELb0ELb0E", r"k_shadow_anyILb0ELb0ELb0ELb0ELb1E"]
+    asm = compile_asm()
     sys.path.insert(0, ROOT)
     from path_tracer_amd.buildinfo import kernel_source_hash
 
