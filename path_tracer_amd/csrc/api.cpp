@@ -696,7 +696,7 @@ int mipt_upload_scene(mipt_ctx *c, const mipt_scene_desc *desc) {
   // 56.6 -> 51.5 ms per 128 spp, cornellBoxes 157.7 -> 154.1); in mesh scenes its one-ray-per-lane walks cost
   // more than the few small launches they replace (100 k triangles +1 %, 1 M +3.5 % at 262144 rays), so it is off there.
   c->tail_rays = c->tail_rays_env >= 0 ? (uint32_t)c->tail_rays_env : (c->n_prims <= 4096 ? (1u << 18) : 0u);
-  c->fuse_rays = c->fuse_rays_env >= 0 ? (uint32_t)c->fuse_rays_env : (c->n_prims > 4096 ? (1u << 17) : 0u);
+  c->fuse_rays = c->fuse_rays_env >= 0 ? (uint32_t)c->fuse_rays_env : (c->n_prims > 4096 ? (1u << 19) : 0u);
   c->lights_host = H.lights;
   c->lights_area_samples = -1;
   c->table_area_samples = -1;
@@ -864,7 +864,8 @@ static int render_core(mipt_ctx *c, const mipt_params *p, double *d_sum, hipStre
         }
         // where this level's shaded hits go: the whole list, or (two streams, few enough rays) one half of it
         // (wide levels fill the chip by themselves and only lose by sharing it: they stay on one stream)
-        const bool halves = overlap && n <= half && n <= c->overlap_rays;
+        const bool fusable = dup == 1 && spilled == 0 && n <= c->fuse_rays && (uint64_t)5 * n + 2048 <= cap;  // see below
+        const bool halves = overlap && n <= half && (n <= c->overlap_rays || fusable);
         hipStream_t sb = halves ? c->shadow_stream : st;
         if (halves) side ^= 1;
         const uint32_t sl_off = halves && side ? half : 0u;
@@ -876,7 +877,7 @@ static int render_core(mipt_ctx *c, const mipt_params *p, double *d_sum, hipStre
         // them.  Its waves work `fuse_budget` rounds at most, which bounds what they can append to the list.
         const bool cam_level = dup > 1;  // the camera rays of a batch of several samples per pixel: one ray and at most one hit per sample
         uint32_t fuse_budget = 0;
-        if (halves && dup == 1 && spilled == 0 && n <= c->fuse_rays && (uint64_t)5 * n + 2048 <= cap)
+        if (halves && fusable)
           fuse_budget = (uint32_t)std::min<uint64_t>(4096, rc_l.shade_capacity / ((uint64_t)tail_grid(rc, n) * 256u));
         const bool fused = fuse_budget >= 48;
         if (!fused) {

@@ -41,7 +41,9 @@ struct DeviceCounters {
 // their own, 256 bytes apart, so that the two streams of atomics do not queue behind each other.
 struct BatchCounts {
   uint32_t next_rays;  // entries appended to the next queue
-  uint32_t pad0[63];
+  uint32_t pad0[31];
+  uint32_t tail_next;  // the finishing launch's input: chunks of it handed out so far
+  uint32_t pad2[31];
   uint32_t shades;     // entries appended to the shade list
   uint32_t overflow;   // a queue was full
   uint32_t pad1[62];
@@ -80,7 +82,7 @@ void launch_shade(const SceneDev &S, const RenderConst &rc, RayQueue q, uint32_t
 // Finishes the path trees of the `n` rays of `q` depth first, wave by wave; rays it does not get to (a wave's
 // budget of rounds, a full wave stack) are appended to `next` and counted in bc->next_rays.
 // sl == null: the launch traces the shadow rays of its shaded hits itself.  Else it appends the hits to *sl
-// (bc->shades counts them) for the shadow kernels, every wave working at most `budget` rounds: the caller
+// (bc->shades counts them) for the shadow kernels, every wave appending at most 64 x `budget` records: the caller
 // makes sure tail_grid(rc, n) x 4 waves x 64 x budget records fit the list.
 unsigned tail_grid(const RenderConst &rc, uint32_t n);
 void launch_tail(const SceneDev &S, const RenderConst &rc, RayQueue q, uint32_t n, RayQueue next, const ShadeList *sl, uint32_t budget, BatchCounts *bc,

@@ -1070,6 +1070,16 @@ __global__ void __launch_bounds__(kBlock) k_shadow_sum_lights(SceneDev S, ShadeL
 // kTailStack + 128 rays beyond its input, so a launch of n rays emits fewer than 5 n + 2048.
 // A sample's direct term is added ray by ray here, hit by hit in k_shadow_sum: the sums differ by
 // the rounding of fp64 additions in another order.
+#ifndef MIPT_TAIL_READY_DIV
+#define MIPT_TAIL_READY_DIV 2  // a wave turns to its path nodes when this share of its walks has ended (1 / 2 / 3 / 4 / 8: 5.9 / 4.3 / 4.3 / 4.8 / 5.8 ms for the launch that starts from 2^17 rays of the benchmark scene)
+#endif
+#ifndef MIPT_TAIL_ROUNDS
+#define MIPT_TAIL_ROUNDS (64 * 4096)  // rounds after which a wave of an exporting launch hands its rays back
+#endif
+#ifndef MIPT_TAIL_CHUNK
+#define MIPT_TAIL_CHUNK 16
+#endif
+constexpr uint32_t kTailChunk = MIPT_TAIL_CHUNK;  // input rays a wave takes at a time (<= 64)
 constexpr int kTailStack = 96;       // pending rays per wave
 constexpr int kTailBudget = 4096;    // rounds (nodes per lane) a wave works before it hands its stack back
 struct TailWaveStack {
@@ -1085,8 +1095,17 @@ struct TailWaveStack {
 
 // EXPORT: the shaded hits are appended to the shade list `sl` (counted in bc->shades) instead of
 // having their shadow rays traced here; the host then runs the shadow kernels once over all of
-// them.  `budget` bounds the rounds of a wave, and with them what the launch can append:
-// waves x 64 x budget records.
+// them.  A wave appends at most 64 x `budget` records, the launch waves x 64 x budget.  The lanes
+// of such a launch do not walk in step: a launch that starts from 2^17 rays of the benchmark scene
+// has chains of fifty and more bounces to follow, and its duration is that of the slowest chain;
+// with every round waiting for the longest of the wave's walks a chain pays the longest of 64 walks
+// per bounce instead of its own.
+#ifdef MIPT_TAIL_DEBUG
+__device__ unsigned long long g_tail_dbg[8192 * 8];
+extern "C" int mipt_debug_tail(unsigned long long *out, int n) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tail_dbg), sizeof(unsigned long long) * (size_t)n);
+}
+#endif
 template <bool WALK, bool LOCAL, bool EXPORT>
 __global__ void __launch_bounds__(kBlock, 2) k_tail(SceneDev S, RenderConst rc, RayQueue q, uint32_t n, RayQueue nq, ShadeList sl, uint32_t budget,
                                                      BatchCounts *bc, double *accum) {
@@ -1095,14 +1114,33 @@ __global__ void __launch_bounds__(kBlock, 2) k_tail(SceneDev S, RenderConst rc, 
   const Stack stack{lds_stack + threadIdx.x, kBlock, blockIdx.x * kBlock + threadIdx.x};
   TailWaveStack &pend = pend_all[threadIdx.x / 64];
   const uint32_t lane = lane_id();
+#ifdef MIPT_TAIL_DEBUG
   const uint32_t wave = blockIdx.x * (kBlock / 64) + threadIdx.x / 64;
-  const uint32_t n_waves = gridDim.x * (kBlock / 64);
+#endif
   TravCounters tc{0, 0};
   uint32_t top = 0;                 // entries on the wave's stack (wave-uniform)
   bool stop = false;                // wave-uniform: out of budget or out of stack, hand everything back
-  uint64_t next_in = (uint64_t)wave * 64ull;  // next input ray of this wave's current chunk
-  uint32_t in_left = 64;            // rays of that chunk not yet taken
-  bool active = false;
+  // The input is handed out in chunks of kTailChunk rays from one counter, to whichever wave has lanes free and
+  // nothing waiting of its own: rays that are neighbours in the queue are neighbours in the scene, and where
+  // hits keep spawning two rays (smooth surfaces) a wave that owned 64 such neighbours had five times the
+  // average wave's work (the launch lasts as long as its slowest wave).
+  uint64_t next_in = 0;             // next input ray of this wave's current chunk
+  uint32_t in_left = 0;             // rays of that chunk not yet taken
+  bool input_done = false;          // the counter has passed the end of the input (wave-uniform)
+  auto next_chunk = [&]() {         // taken when the wave has lanes free for it, not before
+    uint32_t c = 0;
+    if (lane == 0) c = atomicAdd(&bc->tail_next, 1u);
+    c = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
+    next_in = (uint64_t)c * (uint64_t)kTailChunk;
+    input_done = next_in >= (uint64_t)n;
+    in_left = input_done ? 0u : min(kTailChunk, (uint32_t)((uint64_t)n - next_in));
+  };
+  bool active = false;   // the lane holds a ray
+  bool walking = false;  // ... whose closest hit is still being looked for
+  Trav walk;
+  walk.cur = MIPT_TRAV_DONE;
+  walk.sp = 0;
+  uint32_t appended = 0;  // shade records this wave has exported (wave-uniform)
   d3 o{0, 0, 0}, d{0, 0, 1}, T{0, 0, 0};
   uint64_t key = 0;
   uint32_t slot = 0;
@@ -1146,6 +1184,10 @@ __global__ void __launch_bounds__(kBlock, 2) k_tail(SceneDev S, RenderConst rc, 
     if (top + (uint32_t)__popcll(m) > (uint32_t)kTailStack) stop = true;  // at most 64 rays per wave leave this way: the wave ends its work
     top = min(top + (uint32_t)__popcll(m), (uint32_t)kTailStack);
   };
+#ifdef MIPT_TAIL_DEBUG
+  const unsigned long long dbg_t0 = wall_clock64();
+  unsigned long long dbg_walk = 0, dbg_node = 0, dbg_nodes = 0, dbg_rounds = 0, dbg_trounds = 0;
+#endif
   for (int round = 0;; round++) {
     // ---- lanes without a ray take one: from the wave's stack first, then from the input ----
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -1163,15 +1205,22 @@ __global__ void __launch_bounds__(kBlock, 2) k_tail(SceneDev S, RenderConst rc, 
         slot = pend.slot[i];
         depth = (int)pend.depth[i];
         active = true;
+        if (EXPORT) {
+          trav_init(walk, S, o, d, rc.t_max);
+          walking = true;
+        }
       }
       top -= take;
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       __builtin_amdgcn_wave_barrier();
       idle = __ballot(!active);
     }
-    while (idle != 0ull && next_in < (uint64_t)n && !stop) {
-      uint32_t avail = (uint32_t)min((uint64_t)in_left, (uint64_t)n - next_in);
-      uint32_t take = min((uint32_t)__popcll(idle), avail);
+    while (idle != 0ull && !input_done && !stop) {
+      if (in_left == 0u) {
+        next_chunk();
+        if (input_done) break;
+      }
+      uint32_t take = min((uint32_t)__popcll(idle), in_left);
       uint32_t r = rank_below(idle, lane);
       if (!active && r < take) {
         uint64_t i = next_in + r;
@@ -1182,16 +1231,22 @@ __global__ void __launch_bounds__(kBlock, 2) k_tail(SceneDev S, RenderConst rc, 
         slot = q.slot[i];
         depth = (int)q.depth[i];
         active = true;
+        if (EXPORT) {
+          trav_init(walk, S, o, d, rc.t_max);
+          walking = true;
+        }
       }
       next_in += take;
       in_left -= take;
-      if (in_left == 0u || next_in >= (uint64_t)n) {  // on to this wave's next chunk
-        next_in = next_in - (next_in % 64ull == 0ull ? 64ull : next_in % 64ull) + (uint64_t)n_waves * 64ull;
-        in_left = 64;
-      }
       idle = __ballot(!active);
     }
     if (__ballot(active) == 0ull) {
+#ifdef MIPT_TAIL_DEBUG
+      if (lane == 0 && wave < 8192u) {
+        unsigned long long *g = g_tail_dbg + 8ull * wave;
+        g[0] = dbg_t0; g[1] = wall_clock64(); g[2] = dbg_rounds; g[3] = dbg_nodes; g[4] = dbg_walk; g[5] = dbg_node; g[6] = dbg_trounds; g[7] = stop ? 1 : 0;
+      }
+#endif
       if (stop) {
         // out of budget with rays left: hand the stack and this wave's untouched input back
         for (uint32_t b = 0; b < top; b += 64u) {
@@ -1201,32 +1256,73 @@ __global__ void __launch_bounds__(kBlock, 2) k_tail(SceneDev S, RenderConst rc, 
           emit_out(mine, d3{pend.v[0][k], pend.v[1][k], pend.v[2][k]}, d3{pend.v[3][k], pend.v[4][k], pend.v[5][k]},
                    d3{pend.v[6][k], pend.v[7][k], pend.v[8][k]}, pend.key[k], pend.slot[k], (int)pend.depth[k]);
         }
-        while (next_in < (uint64_t)n) {
-          uint32_t avail = (uint32_t)min((uint64_t)in_left, (uint64_t)n - next_in);
-          bool mine = lane < avail;
+        while (!input_done) {  // what is left of this wave's chunk, then the chunks nobody has taken
+          if (in_left == 0u) {
+            next_chunk();
+            if (input_done) break;
+          }
+          bool mine = lane < in_left;
           uint64_t k = mine ? next_in + lane : 0ull;
           emit_out(mine, d3{q.ox[k], q.oy[k], q.oz[k]}, d3{q.dx[k], q.dy[k], q.dz[k]}, d3{q.tx[k], q.ty[k], q.tz[k]}, q.key[k], q.slot[k], (int)q.depth[k]);
-          next_in = next_in - next_in % 64ull + (uint64_t)n_waves * 64ull;
-          in_left = 64;
+          in_left = 0;
         }
       }
       break;
     }
-    // ---- one path node per lane ------------------------------------------------------
-    NodeOut r;
-    r.emitBounce = r.emitMirror = r.emitShade = r.shaded = false;
+    // ---- closest hits -------------------------------------------------------------------------
+    // EXPORT: the walks go on until half of them have ended.  A lane whose walk has ended need not wait for the
+    // longest walk of the wave, only for some more to end with it (the path node costs the wave the same for one
+    // lane as for 64, ~5 us, so turning to it for every single lane serialises the wave's chains instead).
+    // Without EXPORT every lane walks to the end: the lanes then share out the shadow rays of the round's hits,
+    // which use the lanes' traversal stacks.
+    bool ready = active;
     int hprim = -1;
-    if (active) {
+    double ht = 0.0;
+    if (EXPORT) {
+      const uint32_t n_walking = (uint32_t)__popcll(__ballot(walking));
+      const uint32_t want = max(1u, n_walking / (uint32_t)MIPT_TAIL_READY_DIV);
+#ifdef MIPT_TAIL_DEBUG
+      const unsigned long long dbg_a = wall_clock64();
+#endif
+      do {
+        trav_round<false, false, LOCAL>(walk, S, stack, tc);
+#ifdef MIPT_TAIL_DEBUG
+        dbg_trounds++;
+#endif
+      } while ((uint32_t)__popcll(__ballot(walking && walk.cur == MIPT_TRAV_DONE)) < want);
+#ifdef MIPT_TAIL_DEBUG
+      dbg_walk += wall_clock64() - dbg_a;
+#endif
+      ready = walking && walk.cur == MIPT_TRAV_DONE;
+      if (ready) {
+        hprim = walk.best.prim;
+        ht = walk.best.t;
+        walking = false;
+      }
+    } else if (active) {
       Hit h = traverse<false, false, LOCAL>(S, o, d, rc.t_max, stack, tc);
       hprim = h.prim;
-      path_node(S, rc, o, d, T, key, slot, depth, h.prim, h.prim >= 0 ? h.t : 0.0, accum, r);
+      ht = h.t;
     }
+    // ---- one path node per lane whose walk has ended ---------------------------------------
+    NodeOut r;
+    r.emitBounce = r.emitMirror = r.emitShade = r.shaded = false;
+#ifdef MIPT_TAIL_DEBUG
+    const unsigned long long dbg_b = wall_clock64();
+    dbg_rounds++;
+    dbg_nodes += (unsigned long long)__popcll(__ballot(ready));
+#endif
+    if (ready) path_node(S, rc, o, d, T, key, slot, depth, hprim, hprim >= 0 ? ht : 0.0, accum, r);
+#ifdef MIPT_TAIL_DEBUG
+    dbg_node += wall_clock64() - dbg_b;
+#endif
     // ---- the direct diffuse term (material.cpp:111-130): the shadow rays of the round's shaded hits,
     // dealt out over all 64 lanes (a wave that is down to a few long paths would otherwise trace each
     // hit's rays one after the other on one lane) ----
     if (EXPORT) {
-      const bool shade = active && r.emitShade;
+      const bool shade = ready && r.emitShade;
       const unsigned long long sm = __ballot(shade);
+      appended += (uint32_t)__popcll(sm);
       if (sm != 0ull) {
         const uint32_t first = (uint32_t)__ffsll((long long)sm) - 1u;
         uint32_t base = 0;
@@ -1247,7 +1343,7 @@ __global__ void __launch_bounds__(kBlock, 2) k_tail(SceneDev S, RenderConst rc, 
         }
       }
     } else {
-      const bool shade = active && r.emitShade;
+      const bool shade = ready && r.emitShade;
       const unsigned long long sm = __ballot(shade);
       const uint32_t n_shade = (uint32_t)__popcll(sm);
       if (n_shade) {
@@ -1280,7 +1376,7 @@ __global__ void __launch_bounds__(kBlock, 2) k_tail(SceneDev S, RenderConst rc, 
       }
     }
     // ---- children: the bounce ray stays with the lane, the mirror ray goes to the stack ----
-    const bool bounce = active && r.emitBounce, mirror = active && r.emitMirror;
+    const bool bounce = ready && r.emitBounce, mirror = ready && r.emitMirror;
     push(mirror, r.P + MIPT_RAY_EPSILON * r.N, r.rdir, r.Tm, mix64(key, SLOT_CHILD_MIRROR), slot, depth + 1);  // RayTracer.cpp:270-271
     if (bounce) {
       o = r.P + r.wdir * MIPT_RAY_EPSILON;  // RayTracer.cpp:259
@@ -1288,12 +1384,20 @@ __global__ void __launch_bounds__(kBlock, 2) k_tail(SceneDev S, RenderConst rc, 
       T = r.Tb;
       key = mix64(key, SLOT_CHILD_BOUNCE);
       depth = depth + 1;
+      if (EXPORT) {
+        trav_init(walk, S, o, d, rc.t_max);
+        walking = true;
+      }
     }
-    active = bounce;
-    if ((uint32_t)round + 1u >= budget) stop = true;
-    if (stop) {  // the lanes' own rays go back too
+    if (ready) active = bounce;
+    // EXPORT: `budget` bounds the records a wave appends (64 per round of whole waves); a round may add 64 more.
+    // A bound on the rounds themselves, far beyond what any tree needs, lets every wave reach its end whatever happens.
+    if (EXPORT ? (appended + 64u > budget * 64u || round + 1 >= MIPT_TAIL_ROUNDS) : ((uint32_t)round + 1u >= budget)) stop = true;
+    if (stop) {  // the lanes' own rays go back too, walked or not
       emit_out(active, o, d, T, key, slot, depth);
       active = false;
+      walking = false;
+      walk.cur = MIPT_TRAV_DONE;
     }
   }
 }

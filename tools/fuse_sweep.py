@@ -1,5 +1,5 @@
 import os, sys, time
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from path_tracer_amd import abi, synth
 from path_tracer_amd.raytracer import Context
@@ -7,10 +7,12 @@ sc = synth.make_scene(1000000, seed=0xC4)
 ctx = Context(0)
 w, h = 1920, 1080
 d = torch.zeros(3 * w * h, dtype=torch.float64, device="cuda:0")
-for fuse in (0, 1<<12, 1<<14, 1<<15, 1<<16, 1<<17, 1<<18):
+for fuse in [int(x) for x in os.environ.get('FUSE', '0,16384,65536,131072,262144,524288,1048576').split(',')]:
     ctx.set_option("fuse_rays", fuse)
+    if os.environ.get("OVERLAP_FOLLOWS"):
+        ctx.set_option("overlap_rays", max(fuse, 1 << 18))
     ctx.upload_scene(sc)
-    for S in (16,):
+    for S in (16, 128):
         p = abi.default_params(w, h, spp=S, batch_samples=1 << 28, flags=abi.FLAG_PROFILE)
         ctx.render_accumulate(p, d.data_ptr(), 0)
         ctx.reset_counters()
