@@ -1080,18 +1080,26 @@ __global__ void __launch_bounds__(kBlock) k_shadow_sum_lights(SceneDev S, ShadeL
 #define MIPT_TAIL_CHUNK 16
 #endif
 constexpr uint32_t kTailChunk = MIPT_TAIL_CHUNK;  // input rays a wave takes at a time (<= 64)
-constexpr int kTailStack = 96;       // pending rays per wave
 constexpr int kTailBudget = 4096;    // rounds (nodes per lane) a wave works before it hands its stack back
+// STACK: pending rays per wave; HITS: room for the shaded hits of a round (64) where the wave traces their shadow
+// rays itself, else none
+template <int STACK, int HITS>
 struct TailWaveStack {
-  double v[9][kTailStack];  // origin, direction, throughput
-  uint64_t key[kTailStack];
-  uint32_t slot[kTailStack];
-  uint32_t depth[kTailStack];
+  double v[9][STACK];  // origin, direction, throughput
+  uint64_t key[STACK];
+  uint32_t slot[STACK];
+  uint32_t depth[STACK];
   // the shaded hits of the current round, whose shadow rays the wave's lanes share out
-  double hit[9][64];  // P, N, W
-  uint64_t hit_key[64];
-  uint32_t hit_slot[64];
+  double hit[9][HITS];  // P, N, W
+  uint64_t hit_key[HITS];
+  uint32_t hit_slot[HITS];
 };
+#ifndef MIPT_TAIL_EXPORT_WAVES
+#define MIPT_TAIL_EXPORT_WAVES 2  // waves per SIMD the exporting form is compiled for
+#endif
+#ifndef MIPT_TAIL_EXPORT_STACK
+#define MIPT_TAIL_EXPORT_STACK 96
+#endif
 
 // EXPORT: the shaded hits are appended to the shade list `sl` (counted in bc->shades) instead of
 // having their shadow rays traced here; the host then runs the shadow kernels once over all of
@@ -1107,12 +1115,14 @@ extern "C" int mipt_debug_tail(unsigned long long *out, int n) {
 }
 #endif
 template <bool WALK, bool LOCAL, bool EXPORT>
-__global__ void __launch_bounds__(kBlock, 2) k_tail(SceneDev S, RenderConst rc, RayQueue q, uint32_t n, RayQueue nq, ShadeList sl, uint32_t budget,
+__global__ void __launch_bounds__(kBlock, (EXPORT ? MIPT_TAIL_EXPORT_WAVES : 2)) k_tail(SceneDev S, RenderConst rc, RayQueue q, uint32_t n, RayQueue nq, ShadeList sl, uint32_t budget,
                                                      BatchCounts *bc, double *accum) {
   extern __shared__ uint32_t lds_stack[];
-  __shared__ TailWaveStack pend_all[kBlock / 64];
+  constexpr int kTailStack = EXPORT ? MIPT_TAIL_EXPORT_STACK : 96;  // pending rays per wave
+  typedef TailWaveStack<kTailStack, (EXPORT ? 1 : 64)> WaveStack;
+  __shared__ WaveStack pend_all[kBlock / 64];
   const Stack stack{lds_stack + threadIdx.x, kBlock, blockIdx.x * kBlock + threadIdx.x};
-  TailWaveStack &pend = pend_all[threadIdx.x / 64];
+  WaveStack &pend = pend_all[threadIdx.x / 64];
   const uint32_t lane = lane_id();
 #ifdef MIPT_TAIL_DEBUG
   const uint32_t wave = blockIdx.x * (kBlock / 64) + threadIdx.x / 64;
