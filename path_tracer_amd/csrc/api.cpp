@@ -99,6 +99,8 @@ struct mipt_ctx {
   uint32_t overlap_rays = 1u << 18;  // levels with at most this many rays use the second stream (MIPT_OVERLAP_RAYS)
   uint32_t fuse_rays = 0;            // mesh scenes: a level with at most this many rays is followed to the end by one launch that
   long fuse_rays_env = -1;           // exports its shaded hits to the shadow kernels (MIPT_FUSE_RAYS, or -1: chosen at upload)
+  uint32_t fuse_budget_cap = 0;      // MIPT_FUSE_BUDGET: that launch's waves append at most 64 x this many records each, however much room the
+                                     // list has, and the launch is used with any budget >= 1 (tests: waves that stop early and hand rays back)
   mipt_counters totals{};
   // mipt_set_option; -1 = decided by the library (per scene at upload)
   struct Options {
@@ -429,6 +431,10 @@ int mipt_create(mipt_ctx **out, int device) {
   if (const char *e = debug_env("MIPT_FUSE_RAYS")) {
     long v = std::atol(e);
     if (v >= 0 && v <= (1l << 24)) c->fuse_rays_env = v;
+  }
+  if (const char *e = debug_env("MIPT_FUSE_BUDGET")) {
+    long v = std::atol(e);
+    if (v >= 1 && v <= 4096) c->fuse_budget_cap = (uint32_t)v;
   }
   if (const char *e = debug_env("MIPT_OVERLAP_RAYS")) {
     long v = std::atol(e);
@@ -878,8 +884,8 @@ static int render_core(mipt_ctx *c, const mipt_params *p, double *d_sum, hipStre
         const bool cam_level = dup > 1;  // the camera rays of a batch of several samples per pixel: one ray and at most one hit per sample
         uint32_t fuse_budget = 0;
         if (halves && fusable)
-          fuse_budget = (uint32_t)std::min<uint64_t>(4096, rc_l.shade_capacity / ((uint64_t)tail_grid(rc, n) * 256u));
-        const bool fused = fuse_budget >= 48;
+          fuse_budget = (uint32_t)std::min<uint64_t>(c->fuse_budget_cap ? c->fuse_budget_cap : 4096, rc_l.shade_capacity / ((uint64_t)tail_grid(rc, n) * 256u));
+        const bool fused = fuse_budget >= (c->fuse_budget_cap ? 1u : 48u);
         if (!fused) {
           ProfScope ps(c, prof, MIPT_K_INTERSECT, n, st);
           launch_intersect(c->dev, rc, q[cur], n, dup, hit_t, hit_prim, dc, count, dup > 1 ? &cam : nullptr, st);

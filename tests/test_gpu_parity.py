@@ -541,6 +541,45 @@ def test_tail_launch_output_larger_than_a_batch_is_parked(gpu, oracle_lib):
         assert e.code == abi.ERR_LIMIT, e
 
 
+def test_finishing_launch_whose_waves_hand_rays_back(oracle_lib, monkeypatch):
+    """The launch that finishes a mesh scene's narrow levels hands its input out in chunks, lets its lanes walk on their
+    own and exports its shaded hits; a wave whose share of the list is used up stops and hands back its stack, its lanes'
+    rays (walked or not) and, once every wave has stopped, the input nobody took.  With the share cut to 64 and to 256
+    records the launch is repeated many times over what comes back; the frame is the one the plain level loop gives
+    (the same samples), which is the oracle's."""
+    from path_tracer_amd.raytracer import Context
+
+    sc = synth.make_scene(20000, seed=3)
+    orc = oracle_lib.Oracle(sc)
+    p = abi.default_params(96, 64, spp=4, seed=33)
+    ref = orc.render(p, threads=16)
+    frames = []
+    for fuse, budget in (("0", None), ("1048576", "1"), ("1048576", "4"), ("1048576", None)):
+        monkeypatch.setenv("MIPT_FUSE_RAYS", fuse)
+        if budget is None:
+            monkeypatch.delenv("MIPT_FUSE_BUDGET", raising=False)
+        else:
+            monkeypatch.setenv("MIPT_FUSE_BUDGET", budget)
+        ctx = Context(0)
+        try:
+            ctx.upload_scene(sc)
+            ctx.reset_counters()
+            pk = abi.default_params(96, 64, spp=4, seed=33, flags=abi.FLAG_PROFILE)
+            frames.append(ctx.render(pk, want_rgb8=False)[0].astype(np.float64))
+            launches = ctx.kernel_times()["tail"]["launches"]
+            if fuse == "0":
+                assert launches == 0
+            elif budget is not None:
+                assert launches >= 3, launches                             # stopped waves: the launch ran again on what came back
+            else:
+                assert launches >= 1
+        finally:
+            ctx.close()
+    assert_images_match(frames[0], ref)
+    for f in frames[1:]:
+        assert np.abs(f - frames[0]).max() <= 1e-6
+
+
 def test_two_launch_streams_give_the_one_stream_frame(scenes, monkeypatch):
     # narrow levels put their shadow rays on a second stream beside the next level's closest-hit
     # launch; MIPT_OVERLAP=0 keeps everything on the caller's stream.  Same rays, same sums up to
