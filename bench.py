@@ -18,8 +18,10 @@ timed region, where rank 0 also resolves them to the 8-bit frame and copies it t
 host (what RayTracer::traceImage + getBuffer hand back).  --scaling weak keeps per-GPU
 work fixed instead (every rank renders S samples).
 
-Rank 0 prints one JSON line; see DESIGN.md for how `roofline` and `cpu_baseline`
-are defined.
+Rank 0 prints one JSON line.  `roofline` describes the kernel with the most device time (roofline() below:
+three fractions against measured ceilings, the largest names the bound); `cpu_baseline` is the fp64 CPU
+restatement of the reference timed on sampled rows of the same frame, whose pixels also check the GPU's
+(`parity`).
 """
 from __future__ import annotations
 

@@ -98,7 +98,7 @@ def test_npz_round_trip(tmp_path, scenes):
 
 
 def test_fixture_scene_inventory(scenes):
-    # what SURVEY-level inspection of the reference's demo scenes shows
+    # what reading the reference's demo scene files shows (assets/scenes/*.json)
     s = scenes("spheres")
     assert len(s.objects) == 37 and sum(o.type == abi.OBJ_SPHERE for o in s.objects) == 36 and s.lights[0].type == abi.LIGHT_RECT_AREA
     c = scenes("cornellBoxes")
