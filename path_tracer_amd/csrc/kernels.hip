@@ -235,13 +235,20 @@ __device__ __forceinline__ uint32_t xcd_major_block() {
   return (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
 }
 
-// Work feed of a persistent wave: 64-item chunks.  The first `static_rounds` chunks of a wave are
-// its own (chunk numbers wave, wave + W, ...: no shared counter, neighbouring items enter a wave
-// together); the rest of the launch is handed out chunk by chunk from shared counters, so that
-// the waves finish together instead of each ending with its own last chunk (static alone:
-// k_shadow_any 690 ms per step of the benchmark, with a quarter of the rounds dynamic 620 ms).
+// Work feed of a persistent wave: 64-item chunks, drawn a few at a time from a counter.
+// The six waves of a SIMD do not run at the same pace: the one in the lowest wave slot issues first whenever it can, and
+// measured on k_shadow_any (a build with -DMIPT_ANY_DEBUG, tools/experiments/any_wave_stats.py) the waves in slot 0 get
+// through the same number of chunks in 18.2 ms that those in slot 5 need 27.0 ms for.  A share of the chunks that is a wave's
+// own (chunk numbers wave, wave + W, ...: no counter) therefore ends at very different times, and with three quarters of the
+// launch dealt out that way and a quarter drawn from counters 7 % of the launch's wave-slot time idled at its end.  With every
+// chunk drawn from a counter the slow slots simply draw fewer (3500 to 6700 per wave in one launch): 0.15 % idle, the camera
+// level's shadow launch of the benchmark step 220.7 -> 191.9 ms, the step 708 -> 664 ms.  What made "more from the counters"
+// slower when it was first tried (2/8 / 3/8 of the rounds: 498.5 / 502.1 ms) was not the counters but where their chunks lay:
+// a contiguous run of the launch per XCD, so that the eight XCDs worked in eight distant parts of the item sequence; the
+// groups now alternate between the XCDs (below) and the chip moves through the items as one.
+// MIPT_DYNAMIC_TAIL_EIGHTHS < 8 keeps that share of own chunks at the front of the launch (A/B builds).
 #ifndef MIPT_DYNAMIC_TAIL_EIGHTHS
-#define MIPT_DYNAMIC_TAIL_EIGHTHS 2  // share of the rounds handed out dynamically, in eighths (0: none)
+#define MIPT_DYNAMIC_TAIL_EIGHTHS 8  // share of the rounds handed out dynamically, in eighths (0: none)
 #endif
 struct WorkFeed {
   uint64_t base;   // first item of the current chunk
@@ -250,21 +257,46 @@ struct WorkFeed {
   uint32_t static_rounds, wave, n_waves;
   uint32_t tail_first, tail_end;  // chunk numbers of the dynamic part this wave's XCD draws from
   uint32_t part;                  // which of the (up to eight) runs of the dynamic part that is
+  uint32_t grp_next, grp_left;    // the chunks of the group this wave last drew that it has not started
+  uint32_t parts;                 // runs (XCDs) the dynamic part is dealt to
+  uint32_t group;                 // chunks a wave draws at a time
 };
-// The dynamic part is split into eight runs of chunks, one per XCD with a counter of its own:
-// workgroups go to the XCDs round-robin, so the waves that share an L2 keep drawing neighbouring
-// chunks, as they do in the static part (xcd_major_block).  (One counter for the whole chip:
-// half the gain.  Moving on to another XCD's run when the own one is used up: measured slower.)
-__device__ __forceinline__ uint64_t feed_chunk(const WorkFeed &f, unsigned int *counters) {
+#ifndef MIPT_DYN_INTERLEAVE
+#define MIPT_DYN_INTERLEAVE 1  // 0: a contiguous run of the launch per XCD (A/B builds)
+#endif
+#ifndef MIPT_GROUP_CLOSEST
+#define MIPT_GROUP_CLOSEST 4  // most chunks a wave of k_intersect draws from its XCD's counter at a time
+#endif
+#ifndef MIPT_GROUP_ANY
+#define MIPT_GROUP_ANY 6      // the same for k_shadow_any
+#endif
+// One counter per XCD (workgroups go to the XCDs round-robin: blockIdx % 8): one word takes ~90 atomics per microsecond
+// and 6144 waves finish a chunk every ~5 us, so a wave draws a group of chunks per atomic (k_shadow_any alone, groups of
+// 1 / 2 / 4 / 8 chunks: 489 / 458 / 454 / 455 ms per step; k_intersect prefers 2-4: 113-115 against 119 ms at 8) and the
+// counters are eight.  Group v of XCD x is group 8 v + x of the launch.
+__device__ __forceinline__ uint64_t feed_chunk(WorkFeed &f, unsigned int *counters) {
   if (f.round < f.static_rounds) return ((uint64_t)f.round * f.n_waves + f.wave) * 64ull;
-  uint32_t v = 0;
-  if (lane_id() == 0) v = atomicAdd(counters + f.part, 1u);
-  v = (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
-  const uint64_t c = (uint64_t)f.tail_first + v;
+  if (f.grp_left == 0u) {
+    uint32_t v = 0;
+    if (lane_id() == 0) v = atomicAdd(counters + f.part, 1u);
+    v = (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+#if MIPT_DYN_INTERLEAVE
+    const uint64_t first = (uint64_t)f.tail_first + ((uint64_t)v * f.parts + f.part) * (uint64_t)f.group;
+#else
+    const uint64_t first = (uint64_t)f.tail_first + (uint64_t)v * (uint64_t)f.group;
+#endif
+    f.grp_next = (uint32_t)min(first, (uint64_t)f.tail_end);
+    f.grp_left = f.group;
+  }
+  const uint64_t c = f.grp_next;
+  f.grp_next++;
+  f.grp_left--;
   return c < f.tail_end ? c * 64ull : ~0ull;
 }
-__device__ __forceinline__ void feed_init(WorkFeed &f, uint64_t n_items, uint32_t wave, uint32_t n_waves, unsigned int *counters) {
+__device__ __forceinline__ void feed_init(WorkFeed &f, uint64_t n_items, uint32_t wave, uint32_t n_waves, unsigned int *counters, uint32_t max_group) {
   const uint64_t chunks = (n_items + 63ull) / 64ull;
+  // groups as large as allowed while every wave still draws eight or more of them (the launch ends within a group's time)
+  f.group = (uint32_t)min((uint64_t)max_group, max((uint64_t)1, chunks / ((uint64_t)n_waves * 8ull)));
   const uint64_t rounds = chunks / n_waves;  // whole rounds of static chunks
   f.static_rounds = MIPT_DYNAMIC_TAIL_EIGHTHS > 0 ? (uint32_t)(rounds - rounds * MIPT_DYNAMIC_TAIL_EIGHTHS / 8) : 0xffffffffu;
   f.wave = wave;
@@ -274,14 +306,23 @@ __device__ __forceinline__ void feed_init(WorkFeed &f, uint64_t n_items, uint32_
     const uint32_t parts = min(8u, gridDim.x);  // a launch of fewer than eight blocks does not reach every XCD
     const uint64_t len = (chunks - t0 + parts - 1u) / parts;
     f.part = blockIdx.x % parts;
+    f.parts = parts;
+#if MIPT_DYN_INTERLEAVE
+    f.tail_first = (uint32_t)t0;
+    f.tail_end = (uint32_t)chunks;
+    (void)len;
+#else
     f.tail_first = (uint32_t)min(t0 + f.part * len, chunks);
     f.tail_end = (uint32_t)min(t0 + (f.part + 1ull) * len, chunks);
+#endif
   } else {
     f.tail_first = f.tail_end = 0;
     f.part = 0;
+    f.parts = 1;
   }
   f.round = 0;
   f.used = 0;
+  f.grp_next = f.grp_left = 0;
   f.base = feed_chunk(f, counters);
 }
 // Takes up to `want` (<= 64) items: the `got` items handed out are first .. first + n1 - 1 and,
@@ -340,7 +381,7 @@ __global__ void __launch_bounds__(kBlock, MIPT_TRAV_WAVES) k_intersect(SceneDev 
   bool idle = true;
   uint32_t ray = 0;
   WorkFeed feed;
-  feed_init(feed, n, wave, n_waves, dc->dyn_next);
+  feed_init(feed, n, wave, n_waves, dc->dyn_next, MIPT_GROUP_CLOSEST);
   bool exhausted = false;  // wave-uniform
   while (true) {
     unsigned long long idle_mask = __ballot(idle);
@@ -698,12 +739,22 @@ __device__ __forceinline__ int light_of_ray(const SceneDev &S, uint32_t r) {
 // sphere, box and square tests compiled into it, anywhere, this kernel is 7 % slower on the benchmark scene
 // (registers), whose one analytic primitive hardly any shadow ray meets.
 constexpr int kLeanAnalyticMax = 8;
+#ifdef MIPT_ANY_DEBUG
+__device__ unsigned long long g_any_dbg[16384 * 4];  // per wave of the last k_shadow_any launch: start, end, XCD, items of the launch
+extern "C" int mipt_debug_any(unsigned long long *out, int n) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_any_dbg), sizeof(unsigned long long) * (size_t)n);
+}
+#endif
 // NO_TRI: the scene has no triangle at all (the reference's demo scenes): the triangle test and the own-triangle
 // shortcut are not compiled in either (28 B less scratch per lane: spheres.json 674 -> 702 Msamples/s).
 template <bool COUNT, bool LOCAL, bool VIS8, bool LEAN, bool NO_TRI = false>  // VIS8: one-byte records (a kernel of its own: the fp64 one keeps its code and registers)
 __global__ void __launch_bounds__(kBlock, (LEAN ? MIPT_LEAN_WAVES : MIPT_TRAV_WAVES)) k_shadow_any(SceneDev S, RenderConst rc, ShadeList sl, uint32_t first_hit, uint32_t n_items,
                                                                          double *__restrict__ vis, DeviceCounters *dc) {
   extern __shared__ uint32_t lds_stack[];
+#ifdef MIPT_ANY_DEBUG
+  const unsigned long long dbg_t0 = wall_clock64();
+  unsigned long long dbg_tdyn = 0;
+#endif
   const Stack stack{lds_stack + threadIdx.x, kBlock, blockIdx.x * kBlock + threadIdx.x};
   const uint32_t lane = lane_id();
   const uint32_t wave = xcd_major_block() * (kBlock / 64) + threadIdx.x / 64;
@@ -717,12 +768,15 @@ __global__ void __launch_bounds__(kBlock, (LEAN ? MIPT_LEAN_WAVES : MIPT_TRAV_WA
   uint32_t item = 0;
   double scale = 0.0;
   WorkFeed feed;
-  feed_init(feed, n_items, wave, n_waves, dc->dyn_next);
+  feed_init(feed, n_items, wave, n_waves, dc->dyn_next, MIPT_GROUP_ANY);
   bool exhausted = false;
   while (true) {
     unsigned long long idle_mask = __ballot(idle);
     if (idle_mask != 0ull && !exhausted) {
       const FeedTake take = feed_take(feed, (uint32_t)__popcll(idle_mask), n_items, dc->dyn_next);
+#ifdef MIPT_ANY_DEBUG
+      if (dbg_tdyn == 0 && feed.round >= feed.static_rounds) dbg_tdyn = wall_clock64();
+#endif
       exhausted = take.got == 0u;
       const uint32_t rnk = rank_below(idle_mask, lane);
       if (idle && rnk < take.got) {
@@ -781,6 +835,18 @@ __global__ void __launch_bounds__(kBlock, (LEAN ? MIPT_LEAN_WAVES : MIPT_TRAV_WA
     wave_count(&dc->shadow_nodes, tc.nodes);
     wave_count(&dc->shadow_prims, tc.prims);
   }
+#ifdef MIPT_ANY_DEBUG
+  if (lane == 0) {
+    const uint32_t w = blockIdx.x * (kBlock / 64) + threadIdx.x / 64;
+    if (w < 16384u) {
+      g_any_dbg[4ull * w + 0] = dbg_t0;
+      g_any_dbg[4ull * w + 1] = wall_clock64();
+      g_any_dbg[4ull * w + 2] = ((unsigned long long)__builtin_amdgcn_s_getreg(20 | (31 << 11)) & 0xf) | ((unsigned long long)(feed.round - min(feed.round, feed.static_rounds)) << 8) |
+                                ((unsigned long long)(__builtin_amdgcn_s_getreg(4 | (31 << 11)) & 0xffffu) << 40);
+      g_any_dbg[4ull * w + 3] = dbg_tdyn;
+    }
+  }
+#endif
 }
 
 // A light record read through the scalar data path: `p` must be the same for every lane of the wave.  The
@@ -897,19 +963,27 @@ __global__ void __launch_bounds__(kBlock, 2) k_shadow_walk(SceneDev S, RenderCon
   const Stack stack{lds_stack + threadIdx.x, kBlock, blockIdx.x * kBlock + threadIdx.x};
   TravCounters tc{0, 0};
   const uint32_t R = (uint32_t)S.rays_per_hit;
-  for (uint64_t it = stack.gtid; it < n_items; it += (uint64_t)gridDim.x * kBlock) {
-    uint64_t w = first_item + it;
-    uint32_t h = (uint32_t)(w / R);
-    uint32_t r = (uint32_t)(w - (uint64_t)h * R);
-    int li = light_of_ray(S, r);
-    const LightRec &L = S.lights[li];
-    d3 P{sl.px[h], sl.py[h], sl.pz[h]};
-    d3 N{sl.nx[h], sl.ny[h], sl.nz[h]};
-    d3 fire = P + (N * MIPT_RAY_EPSILON) * 3.0;
-    d3 light = shadow_ray<COUNT, true, LOCAL>(S, rc, L, li, (int)r - L.first_ray, fire, sl.key[h], stack, tc);
-    vis3[3ull * it + 0] = light.x;
-    vis3[3ull * it + 1] = light.y;
-    vis3[3ull * it + 2] = light.z;
+  // a wave takes 64 items at a time from the work feed (its lanes walk in step: no ray replacement here)
+  WorkFeed feed;
+  feed_init(feed, n_items, blockIdx.x * (kBlock / 64) + threadIdx.x / 64, gridDim.x * (kBlock / 64), dc->dyn_next, MIPT_GROUP_CLOSEST);
+  for (;;) {
+    const FeedTake take = feed_take(feed, 64u, n_items, dc->dyn_next);
+    if (take.got == 0u) break;
+    const uint64_t it = feed_item(take, lane_id());
+    if (lane_id() < take.got && it < n_items) {  // (the feed's calls above are made by the whole wave)
+      uint64_t w = first_item + it;
+      uint32_t h = (uint32_t)(w / R);
+      uint32_t r = (uint32_t)(w - (uint64_t)h * R);
+      int li = light_of_ray(S, r);
+      const LightRec &L = S.lights[li];
+      d3 P{sl.px[h], sl.py[h], sl.pz[h]};
+      d3 N{sl.nx[h], sl.ny[h], sl.nz[h]};
+      d3 fire = P + (N * MIPT_RAY_EPSILON) * 3.0;
+      d3 light = shadow_ray<COUNT, true, LOCAL>(S, rc, L, li, (int)r - L.first_ray, fire, sl.key[h], stack, tc);
+      vis3[3ull * it + 0] = light.x;
+      vis3[3ull * it + 1] = light.y;
+      vis3[3ull * it + 2] = light.z;
+    }
   }
   if (COUNT) {
     wave_count(&dc->shadow_nodes, tc.nodes);
@@ -1616,6 +1690,7 @@ void launch_shadow_trace(const SceneDev &S, const RenderConst &rc, ShadeList sl,
   uint32_t items = (uint32_t)(n_hits * R);
   if (S.translucent) {
     auto kern = S.local_meshes ? (count ? k_shadow_walk<true, true> : k_shadow_walk<false, true>) : (count ? k_shadow_walk<true, false> : k_shadow_walk<false, false>);
+    (void)hipMemsetAsync(dc->dyn_next, 0, sizeof(dc->dyn_next), st);
     hipLaunchKernelGGL(kern, dim3(persistent_grid(S, rc, items)), dim3(kBlock), stack_bytes(S), st, S, rc, sl, first_hit * R, items, vis, dc);
   } else {
     const bool lean = S.lean_any != 0 && S.n_analytic <= kLeanAnalyticMax;
