@@ -11,7 +11,7 @@ ctx = Context(0); ctx.upload_scene(sc)
 w, h = 1920, 1080
 d = torch.zeros(3*w*h, dtype=torch.float64, device="cuda:0")
 for spp in (int(x) for x in os.environ.get("SPP", "16").split(",")):
-    p = abi.default_params(w, h, spp=spp, batch_samples=1 << 28, max_depth=1)
+    p = abi.default_params(w, h, spp=spp, batch_samples=1 << 28, max_depth=int(os.environ.get('DEPTH', '1')))
     for _ in range(2): ctx.render_accumulate(p, d.data_ptr(), 0)
     torch.cuda.synchronize()
     lib = ctx.lib
@@ -26,7 +26,7 @@ for spp in (int(x) for x in os.environ.get("SPP", "16").split(",")):
     a = a.astype(np.float64); a[:,2] = xcd
     t0 = a[:,0].min(); st = (a[:,0]-t0)/100.0; en = (a[:,1]-t0)/100.0
     span = en.max()
-    print(f"{spp} spp, camera level: {len(a)} waves, {a[0,3]:.0f} shadow rays, launch span {span:.0f} us")
+    print(f"{spp} spp, last level of max_depth {os.environ.get('DEPTH', '1')}: {len(a)} waves, {a[0,3]:.0f} shadow rays, launch span {span:.0f} us")
     print("  wave start us: p50 %.0f p99 %.0f max %.0f;  wave end us: min %.0f p1 %.0f p10 %.0f p50 %.0f p90 %.0f max %.0f" % (*np.percentile(st,[50,99]), st.max(), en.min(), *np.percentile(en,[1,10,50,90]), en.max()))
     print("  wave-slot time idle at the end: %.2f %% of slots x span;  at the start %.2f %%" % (100*(span-en).sum()/(span*len(a)), 100*st.sum()/(span*len(a))))
     td = (tdyn - t0)/100.0
