@@ -267,13 +267,18 @@ struct WorkFeed {
 #ifndef MIPT_GROUP_CLOSEST
 #define MIPT_GROUP_CLOSEST 4  // most chunks a wave of k_intersect draws from its XCD's counter at a time
 #endif
+#ifndef MIPT_GROUP_DIV
+#define MIPT_GROUP_DIV 8      // ... and at least this many groups per wave and launch
+#endif
 #ifndef MIPT_GROUP_ANY
 #define MIPT_GROUP_ANY 6      // the same for k_shadow_any
 #endif
 // One counter per XCD (workgroups go to the XCDs round-robin: blockIdx % 8): one word takes ~90 atomics per microsecond
 // and 6144 waves finish a chunk every ~5 us, so a wave draws a group of chunks per atomic (k_shadow_any alone, groups of
 // 1 / 2 / 4 / 8 chunks: 489 / 458 / 454 / 455 ms per step; k_intersect prefers 2-4: 113-115 against 119 ms at 8) and the
-// counters are eight.  Group v of XCD x is group 8 v + x of the launch.
+// counters are eight.  Group v of XCD x is group 8 v + x of the launch.  (Smaller groups towards the end of a launch, so that
+// it ends within a chunk's time rather than a group's, halve what idles at the end of a mid-sized launch, 5.5 -> 2.3 % of the
+// wave slots at 65 chunks per wave, and cost k_intersect 4 % as a whole: not kept.)
 __device__ __forceinline__ uint64_t feed_chunk(WorkFeed &f, unsigned int *counters) {
   if (f.round < f.static_rounds) return ((uint64_t)f.round * f.n_waves + f.wave) * 64ull;
   if (f.grp_left == 0u) {
@@ -295,8 +300,8 @@ __device__ __forceinline__ uint64_t feed_chunk(WorkFeed &f, unsigned int *counte
 }
 __device__ __forceinline__ void feed_init(WorkFeed &f, uint64_t n_items, uint32_t wave, uint32_t n_waves, unsigned int *counters, uint32_t max_group) {
   const uint64_t chunks = (n_items + 63ull) / 64ull;
-  // groups as large as allowed while every wave still draws eight or more of them (the launch ends within a group's time)
-  f.group = (uint32_t)min((uint64_t)max_group, max((uint64_t)1, chunks / ((uint64_t)n_waves * 8ull)));
+  // groups as large as allowed while every wave still draws MIPT_GROUP_DIV or more of them (the launch ends within a group's time)
+  f.group = (uint32_t)min((uint64_t)max_group, max((uint64_t)1, chunks / ((uint64_t)n_waves * (uint64_t)MIPT_GROUP_DIV)));
   const uint64_t rounds = chunks / n_waves;  // whole rounds of static chunks
   f.static_rounds = MIPT_DYNAMIC_TAIL_EIGHTHS > 0 ? (uint32_t)(rounds - rounds * MIPT_DYNAMIC_TAIL_EIGHTHS / 8) : 0xffffffffu;
   f.wave = wave;
@@ -361,6 +366,12 @@ __device__ __forceinline__ uint32_t rank_below(unsigned long long mask, uint32_t
   return (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
 }
 
+#ifdef MIPT_ANY_DEBUG
+__device__ unsigned long long g_isect_dbg[16384 * 4];  // per wave of the last k_intersect launch: start, end, XCD | chunks << 8 | hw id << 40, rays
+extern "C" int mipt_debug_isect(unsigned long long *out, int n) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_isect_dbg), sizeof(unsigned long long) * (size_t)n);
+}
+#endif
 // `dup` > 1: the queue holds runs of `dup` identical rays (the camera rays of one pixel's
 // samples, RayTracer.cpp:72-75 calls trace(x, y) N times with the same x, y); only the first
 // ray of every run is traced, k_shade reads its result for the whole run.  n = rays to trace.
@@ -370,6 +381,9 @@ __global__ void __launch_bounds__(kBlock, MIPT_TRAV_WAVES) k_intersect(SceneDev 
                                                                         double *__restrict__ hit_t, int *__restrict__ hit_prim, DeviceCounters *dc,
                                                                         CameraRays cam) {
   extern __shared__ uint32_t lds_stack[];
+#ifdef MIPT_ANY_DEBUG
+  const unsigned long long dbg_t0 = wall_clock64();
+#endif
   const Stack stack{lds_stack + threadIdx.x, kBlock, blockIdx.x * kBlock + threadIdx.x};
   const uint32_t lane = lane_id();
   const uint32_t wave = xcd_major_block() * (kBlock / 64) + threadIdx.x / 64;
@@ -422,6 +436,18 @@ __global__ void __launch_bounds__(kBlock, MIPT_TRAV_WAVES) k_intersect(SceneDev 
     wave_count(&dc->closest_nodes, tc.nodes);
     wave_count(&dc->closest_prims, tc.prims);
   }
+#ifdef MIPT_ANY_DEBUG
+  if (lane == 0) {
+    const uint32_t w = blockIdx.x * (kBlock / 64) + threadIdx.x / 64;
+    if (w < 16384u) {
+      g_isect_dbg[4ull * w + 0] = dbg_t0;
+      g_isect_dbg[4ull * w + 1] = wall_clock64();
+      g_isect_dbg[4ull * w + 2] = ((unsigned long long)__builtin_amdgcn_s_getreg(20 | (31 << 11)) & 0xf) | ((unsigned long long)feed.round << 8) |
+                                  ((unsigned long long)(__builtin_amdgcn_s_getreg(4 | (31 << 11)) & 0xffffu) << 40);
+      g_isect_dbg[4ull * w + 3] = n;
+    }
+  }
+#endif
 }
 
 // ------------------------------------------------------------------- shade ----
