@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Soak run of the randomised GPU-vs-oracle comparison (tests/test_gpu_fuzz.py::check_scene) over a range
 of seeds that the test suite does not use; prints every seed that fails and why, and a summary.
-usage (on a GPU box): python tools/fuzz_soak.py FIRST LAST [--local-units]"""
+usage (on a GPU box): python tools/fuzz_soak.py FIRST LAST"""
 import os
 import sys
 import time
