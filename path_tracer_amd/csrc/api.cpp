@@ -808,11 +808,12 @@ static int render_core(mipt_ctx *c, const mipt_params *p, double *d_sum, hipStre
     for (int s0 = p->sample_begin; s0 < p->sample_end; s0 += SB) {
       int ns = std::min(SB, p->sample_end - s0);
       uint32_t n = (uint32_t)((int64_t)npix * ns);
-      HIP_TRY(c, hipMemsetAsync(accum, 0, (size_t)n * 3 * sizeof(double), st));
       // a batch of several samples per pixel never stores its camera rays: the level that traces and shades
-      // them computes them from their index
+      // them computes them from their index, and stores every sample's first term (k_shade<CAM>) so that the
+      // sums need no clearing; a batch of one sample per pixel goes through the queue and adds to cleared sums
       const CameraRays cam{d_rows, p0, npix, s0, ns};
       if (ns == 1) {
+        HIP_TRY(c, hipMemsetAsync(accum, 0, (size_t)n * 3 * sizeof(double), st));
         ProfScope ps(c, prof, MIPT_K_GENERATE, n, st);
         launch_generate(c->dev, rc, d_rows, p0, npix, s0, ns, q[0], st);
       }
