@@ -998,7 +998,7 @@ int mipt_render_accumulate(mipt_ctx *c, const mipt_params *p, double *d_sum, voi
     HIP_TRY(c, hipMemGetInfo(&free_b, &total_b));
     const size_t held = c->queue[0].bytes + c->queue[1].bytes + c->shade.bytes + c->hits.bytes + c->accum.bytes + c->vis.bytes;
     const double per_sample = 4.0 * (double)kEntryBytes + 2.0 * (sizeof(double) + sizeof(int)) + (double)kShadeEntryBytes + 3.0 * sizeof(double) +
-                              (double)std::max(1, c->dev.rays_per_hit) * sizeof(double) * (c->dev.translucent ? 3.0 : 1.0);
+                              (double)std::max(1, c->dev.rays_per_hit) * (c->dev.translucent ? 24.0 : (c->dev.vis_bytes ? 1.0 : 8.0));
     const double fit = 0.6 * (double)(free_b + held) / per_sample;
     ws.batch = (int64_t)std::min<double>((double)(1ll << 28), std::max<double>((double)(1 << 20), fit));
   }
@@ -1019,7 +1019,8 @@ int mipt_render_accumulate(mipt_ctx *c, const mipt_params *p, double *d_sum, voi
   // visibility scratch: all shadow rays of a level (at most `batch` hits) if they fit 2^31 rays, else chunks of whole hits
   uint64_t rays_per_hit = (uint64_t)std::max(1, c->dev.rays_per_hit);
   ws.vis_rays = std::max<uint64_t>(std::min<uint64_t>((uint64_t)(batch + 1024) * rays_per_hit, 1ull << 31), rays_per_hit);
-  if ((r = ensure(c, c->vis, ws.vis_rays * sizeof(double) * (c->dev.translucent ? 3 : 1))) != MIPT_OK) return r;
+  // per ray: one byte where a record says "reached its light or not" (SceneDev::vis_bytes), else a double, three in translucent scenes
+  if ((r = ensure(c, c->vis, ws.vis_rays * (c->dev.translucent ? 3 * sizeof(double) : (c->dev.vis_bytes ? 1 : sizeof(double))) + 64)) != MIPT_OK) return r;
   if (!c->dcount.p) {
     if ((r = ensure(c, c->dcount, 2 * sizeof(DeviceCounters))) != MIPT_OK) return r;  // the second one: work counters of the shadow stream
     HIP_TRY(c, hipMemset(c->dcount.p, 0, 2 * sizeof(DeviceCounters)));

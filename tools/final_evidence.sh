@@ -1,15 +1,10 @@
+# The round's evidence on the final sources, in two halves that each fit one GPU call of twenty minutes:
+#   a: the GPU suite, the counter passes and the bench line of config 4, the workspace a default batch takes
+#   b: the counter passes and the bench line of config 5, the bench lines of the other workloads
+# usage (on a GPU box): bash tools/final_evidence.sh [a|b]   (no argument: both)
 set -e
-mkdir -p gpurun_out/final
-bash tools/profile_round.sh gpurun_out/prof_1m r03 synth1m > gpurun_out/prof_1m.log 2>&1
-cp gpurun_out/prof_1m/counters.json profiles/counters.json
-bash tools/profile_round.sh gpurun_out/prof_10m r03 synth10m --spp-per-step 8 --steps 2 > gpurun_out/prof_10m.log 2>&1
-cp gpurun_out/prof_10m/counters.json profiles/counters.json
-cp profiles/counters.json gpurun_out/final/counters.json
-timeout -k 10 300 python bench.py --steps 20 --warmup 5 > gpurun_out/final/bench_synth1m.json 2> gpurun_out/final/bench_synth1m.err
-timeout -k 10 400 python bench.py --workload synth10m --spp-per-step 8 --steps 2 --no-cpu-baseline > gpurun_out/final/bench_synth10m.json 2> gpurun_out/final/bench_synth10m.err
-: > gpurun_out/final/other.jsonl
-for w in spheres cornell hitchcock cornell_area hitchcock_mesh; do
-  timeout -k 10 200 python bench.py --workload $w --no-cpu-baseline >> gpurun_out/final/other.jsonl 2>> gpurun_out/final/other.err
-done
-timeout -k 10 300 python bench.py --workload synth1m_glossy_terrain --max-depth 8 --no-cpu-baseline >> gpurun_out/final/other.jsonl 2>> gpurun_out/final/other.err
-echo done
+case "${1:-ab}" in
+  a) bash tools/final_evidence_a.sh ;;
+  b) bash tools/final_evidence_b.sh ;;
+  *) bash tools/final_evidence_a.sh && bash tools/final_evidence_b.sh ;;
+esac
