@@ -10,13 +10,13 @@ with scene, queues and the radiance sum resident in HBM.  Metric: path samples/s
 a camera ray plus its whole tree of bounce, mirror and shadow rays).
 
 With N > 1 (one rank per GPU: launched by torch.distributed.run, or by bench.py itself when it is
-started without a launcher) the SAME job is split N
-ways (strong scaling: a step is the same S samples of every pixel whatever N is; every
-rank renders S / N of them for the whole frame, or with --sharding tiles all S for its own
-bands of rows) and the per-pixel sums are brought to rank 0 over RCCL once, inside the
-timed region, where rank 0 also resolves them to the 8-bit frame and copies it to the
-host (what RayTracer::traceImage + getBuffer hand back).  --scaling weak keeps per-GPU
-work fixed instead (every rank renders S samples).
+started without a launcher) the SAME job — the K steps — is split N ways (strong scaling): every rank renders a
+contiguous N-th of the job's sample range for the whole frame, in calls of at most S samples per pixel (or, with
+--sharding tiles, all of the job's samples for its own bands of rows), and the per-pixel sums are brought to
+rank 0 over RCCL once, inside the timed region, where rank 0 also resolves them to the 8-bit frame and copies
+it to the host (what RayTracer::traceImage + getBuffer hand back).  --split-each-step splits every step N
+ways instead (calls of S / N samples per pixel); --scaling weak keeps per-GPU work fixed (every rank renders
+K whole steps).
 
 Rank 0 prints one JSON line.  `roofline` describes the kernel with the most device time (roofline() below:
 three fractions against measured ceilings, the largest names the bound); `cpu_baseline` is the fp64 CPU
@@ -161,6 +161,8 @@ def main():
     ap.add_argument("--sharding", default="samples", choices=["samples", "tiles"],
                     help="N > 1: 'samples' = every rank renders the whole frame for its own samples (reduce); "
                          "'tiles' = every rank renders all samples of its own bands of rows (gather; strong scaling only)")
+    ap.add_argument("--split-each-step", action="store_true",
+                    help="N > 1, strong scaling: split every step N ways (calls of S / N samples per pixel) instead of the job")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo rehearses the N>1 path with several ranks on one GPU (RCCL needs one GPU per rank)")
     ap.add_argument("--max-depth", type=int, default=0, help="0 = the library's default (64)")
@@ -228,7 +230,7 @@ def main():
     # One step = S samples of every pixel.  The deep, nearly empty levels of a batch cost the same
     # ~16 ms whatever its size, so S is as large as the free HBM of one GPU allows (about 700 B per
     # sample with the shadow-ray scratch); every rank takes the smallest choice of any rank.  S does
-    # not depend on N: with N ranks a step is the same S samples, split N ways (strong scaling).
+    # not depend on N: with N ranks the job is the same K steps of S samples (strong scaling).
     S = args.spp_per_step
     if S <= 0:
         free_b = torch.cuda.mem_get_info(local_rank)[0]
@@ -244,10 +246,34 @@ def main():
     if not weak and not tiles and S % world:
         S = max(world, S - S % world)  # every rank gets the same number of samples
     step_spp = S * world if weak else S  # samples per pixel one step adds to the frame, all ranks together
-    per_rank_samples = (S if (weak or tiles) else S // world) * w * h
-    batch = args.batch_samples if args.batch_samples > 0 else min(1 << 28, max(1 << 20, per_rank_samples))
     K, W = args.steps, args.warmup
-    total_spp = (K + W + 2) * step_spp  # the job the steps are slices of (+2: the untimed counter and plain steps)
+    # The timed job: K steps = samples [W * step_spp, (W + K) * step_spp) of every pixel.  One rank renders it step by
+    # step, one call per step.  N ranks split THE JOB, as mipt_dist_render and dist.shard_params split a frame: by samples,
+    # rank r takes a contiguous N-th of the job's sample range and renders it in calls of at most S samples per pixel (the
+    # batch one GPU holds); by tiles, it takes its bands of rows for the whole range, N steps' samples to a call (again one
+    # full batch).  Splitting every step N ways instead (--split-each-step, what this script did before) hands each rank
+    # calls of S / N samples per pixel, whose narrow tree levels cost what a full batch's do: 93.3 ms per 16 spp call
+    # against 661 / 8 = 82.7 on the benchmark scene.  Weak scaling: every rank renders K whole steps.
+    job_lo, job_hi = W * step_spp, (W + K) * step_spp
+    shard_tiles = tiles
+    if world == 1 or weak or args.split_each_step:
+        if weak:
+            calls = [(job_lo + k * step_spp + rank * S, job_lo + k * step_spp + (rank + 1) * S) for k in range(K)]
+        elif tiles or world == 1:
+            calls = [(job_lo + k * S, job_lo + (k + 1) * S) for k in range(K)]
+        else:
+            calls = [(job_lo + k * S + (S * rank) // world, job_lo + k * S + (S * (rank + 1)) // world) for k in range(K)]
+    elif tiles:
+        calls = [(c, min(c + world * S, job_hi)) for c in range(job_lo, job_hi, world * S)]
+    else:
+        lo, hi = job_lo + (K * S * rank) // world, job_lo + (K * S * (rank + 1)) // world
+        calls = [(c, min(c + S, hi)) for c in range(lo, hi, S)]
+    calls = [c for c in calls if c[1] > c[0]]
+    call_spp = max([b - a for a, b in calls] + [1])
+    pixels_mine = (w * h + world - 1) // world if shard_tiles else w * h
+    per_call_samples = call_spp * pixels_mine
+    batch = args.batch_samples if args.batch_samples > 0 else min(1 << 28, max(1 << 20, per_call_samples))
+    total_spp = job_hi + 2 * max(call_spp, step_spp) + step_spp  # room behind the job for the untimed plain and counter calls
     base = abi.default_params(w, h, spp=total_spp, batch_samples=batch)
     if args.max_depth > 0:
         base.max_depth = args.max_depth
@@ -258,11 +284,11 @@ def main():
 
     extra_flags = abi.FLAG_CULL_NEGLIGIBLE if args.cull_negligible else 0
 
-    def step_params(step, flags):
-        whole = abi.default_params(w, h, spp=total_spp, batch_samples=batch)
-        whole.max_depth = base.max_depth
-        whole.sample_begin, whole.sample_end = step * step_spp, (step + 1) * step_spp
-        p = shard_params(whole, rank, world, mode)
+    def call_params(begin, end, flags):
+        p = abi.default_params(w, h, spp=total_spp, batch_samples=batch, sample_begin=begin, sample_end=end)
+        p.max_depth = base.max_depth
+        if shard_tiles:
+            p.shard_index, p.shard_count = rank, world
         p.flags = flags | extra_flags
         return p
 
@@ -279,8 +305,8 @@ def main():
             return d_rgb8.cpu()
         return None
 
-    for s in range(W):
-        ctx.render_accumulate(step_params(s, 0), d_sum.data_ptr(), stream)
+    for s in range(W):  # untimed: calls of the size of the timed ones
+        ctx.render_accumulate(call_params(0, call_spp, 0), d_sum.data_ptr(), stream)
     if W > 0:
         finish(W * step_spp)  # once, untimed: RCCL sets up its channels and buffers on first use
         d_sum.zero_()
@@ -288,8 +314,8 @@ def main():
     prof_flag = 0 if args.no_profile_events else abi.FLAG_PROFILE
     sync()
     t0 = time.perf_counter()
-    for s in range(W, W + K):
-        ctx.render_accumulate(step_params(s, prof_flag), d_sum.data_ptr(), stream)
+    for a, b in calls:
+        ctx.render_accumulate(call_params(a, b, prof_flag), d_sum.data_ptr(), stream)
     frame8 = finish(K * step_spp)
     torch.cuda.synchronize()
     if world > 1:
@@ -300,12 +326,13 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ktimes = ctx.kernel_times()
+    n_calls = max(1, len(calls))
 
-    # one more step without the per-kernel events, timed by itself: what the events cost
+    # one more call without the per-kernel events, timed by itself: what the events cost
     scratch = torch.zeros_like(d_sum)
     sync()
     t1 = time.perf_counter()
-    ctx.render_accumulate(step_params(W + K, 0), scratch.data_ptr(), stream)
+    ctx.render_accumulate(call_params(job_hi, job_hi + call_spp, 0), scratch.data_ptr(), stream)
     torch.cuda.synchronize()
     plain_step_ms = (time.perf_counter() - t1) * 1e3
 
@@ -314,11 +341,11 @@ def main():
         # one instrumented (untimed) step for the work counters; the work is deterministic
         ctx.reset_counters()
         scratch.zero_()
-        ctx.render_accumulate(step_params(W + K + 1, abi.FLAG_COUNTERS), scratch.data_ptr(), stream)
+        ctx.render_accumulate(call_params(job_hi + call_spp, job_hi + 2 * call_spp, abi.FLAG_COUNTERS), scratch.data_ptr(), stream)
         torch.cuda.synchronize()
         cnt = ctx.counters()
         del scratch
-        step_samples = max(1, cnt["samples"])  # rank 0's share of one step
+        step_samples = max(1, cnt["samples"])  # one call of rank 0 (N = 1: one step)
         cnt["shaded_records"] = cnt["shadow_rays"] // max(1, scene_rays_per_hit(scene, base.area_samples))
         out = {
             "metric": "path samples/s",
@@ -336,7 +363,12 @@ def main():
             "config": {
                 "workload": label,
                 "spp_per_step": step_spp,
-                "spp_per_step_per_rank": S if (weak or tiles) else S // world,
+                "calls_per_rank": n_calls,
+                "spp_per_call": call_spp,
+                "job_split": ("none" if world == 1 else "every rank renders K whole steps" if weak else
+                              "every step split N ways" if args.split_each_step else
+                              "the job's sample range in contiguous shares, one per rank" if not tiles else
+                              "every rank renders its bands of rows for the whole job, N steps' samples to a call"),
                 "batch_samples": int(batch),
                 "nominal_spp": nominal_spp,
                 "rr_q": base.rr_q,
@@ -350,7 +382,7 @@ def main():
                 "timed_region": "K x mipt_render_accumulate + the collective + mipt_resolve to RGB8 + its copy to the host",
             },
             "frame_checksum": int(frame8.to(torch.int64).sum().item()),
-            "per_kernel_events_cost": {"ms_per_step_with_events": elapsed / K * 1e3, "ms_of_one_step_without": plain_step_ms},
+            "per_kernel_events_cost": {"ms_per_call_with_events": elapsed / n_calls * 1e3, "ms_of_one_call_without": plain_step_ms},
             "per_sample": {
                 "path_rays": cnt["path_rays"] / step_samples,
                 "shadow_rays": cnt["shadow_rays"] / step_samples,
@@ -364,9 +396,10 @@ def main():
             "kernel_source_hash": kernel_source_hash(),
         }
         if not args.no_profile_events:
-            out["roofline"] = roofline(args.workload, stats["device_bytes"], ktimes, K, cnt, step_samples)
-            out["kernel_ms_per_step"] = {k: v["ms"] / K for k, v in ktimes.items()}
-            out["kernel_launches_per_step"] = {k: v["launches"] / K for k, v in ktimes.items()}
+            # per call of rank 0 (N = 1: per step); the counters above are one such call's
+            out["roofline"] = roofline(args.workload, stats["device_bytes"], ktimes, n_calls, cnt, step_samples)
+            out["kernel_ms_per_step"] = {k: v["ms"] / n_calls for k, v in ktimes.items()}
+            out["kernel_launches_per_step"] = {k: v["launches"] / n_calls for k, v in ktimes.items()}
         if world == 1 and not (args.no_cpu_baseline and args.no_parity):
             # without the baseline leg the oracle still checks a few sampled rows of the workload (a shorter run of the same routine)
             cb, p_cpu, img_cpu = cpu_baseline(scene, base, args.cpu_budget if not args.no_cpu_baseline else min(args.cpu_budget, 4.0))
