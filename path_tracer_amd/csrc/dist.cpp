@@ -136,10 +136,6 @@ int mipt_dist_render(mipt_dist *d, mipt_ctx *ctx, const mipt_params *whole, int 
   if (d->size > 1) {
     if (mode == MIPT_SHARD_SAMPLES) {
       NCCL_OK(ncclReduce(d_sum, d_sum, n, ncclDouble, ncclSum, 0, d->comm, d->stream));
-    } else if ((whole->height + whole->band_rows - 1) / whole->band_rows > 1024) {
-      // very many thin bands: one reduce instead of thousands of point-to-point transfers in one group.  A rank's
-      // buffer is zero outside its own bands, so the sum is the gather, bit for bit (x + 0 = x).
-      NCCL_OK(ncclReduce(d_sum, d_sum, n, ncclDouble, ncclSum, 0, d->comm, d->stream));
     } else {
       // band b = rows [b * band_rows, ...) belongs to rank b % size: a contiguous run of the buffer per band
       const int bands = (whole->height + whole->band_rows - 1) / whole->band_rows;
