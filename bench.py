@@ -243,8 +243,8 @@ def main():
             if cand * w * h * 700 + (40 << 30) <= free_b and cand * w * h <= (1 << 28):
                 S = cand
                 break
-    if not weak and not tiles and S % world:
-        S = max(world, S - S % world)  # every rank gets the same number of samples
+    if args.split_each_step and not weak and not tiles and S % world:
+        S = max(world, S - S % world)  # every rank gets the same number of samples of every step
     step_spp = S * world if weak else S  # samples per pixel one step adds to the frame, all ranks together
     K, W = args.steps, args.warmup
     # The timed job: K steps = samples [W * step_spp, (W + K) * step_spp) of every pixel.  One rank renders it step by
@@ -256,19 +256,7 @@ def main():
     # against 661 / 8 = 82.7 on the benchmark scene.  Weak scaling: every rank renders K whole steps.
     job_lo, job_hi = W * step_spp, (W + K) * step_spp
     shard_tiles = tiles
-    if world == 1 or weak or args.split_each_step:
-        if weak:
-            calls = [(job_lo + k * step_spp + rank * S, job_lo + k * step_spp + (rank + 1) * S) for k in range(K)]
-        elif tiles or world == 1:
-            calls = [(job_lo + k * S, job_lo + (k + 1) * S) for k in range(K)]
-        else:
-            calls = [(job_lo + k * S + (S * rank) // world, job_lo + k * S + (S * (rank + 1)) // world) for k in range(K)]
-    elif tiles:
-        calls = [(c, min(c + world * S, job_hi)) for c in range(job_lo, job_hi, world * S)]
-    else:
-        lo, hi = job_lo + (K * S * rank) // world, job_lo + (K * S * (rank + 1)) // world
-        calls = [(c, min(c + S, hi)) for c in range(lo, hi, S)]
-    calls = [c for c in calls if c[1] > c[0]]
+    calls = plan_calls(K, W, S, world, rank, tiles=tiles, weak=weak, split_each_step=args.split_each_step)
     call_spp = max([b - a for a, b in calls] + [1])
     pixels_mine = (w * h + world - 1) // world if shard_tiles else w * h
     per_call_samples = call_spp * pixels_mine
@@ -425,6 +413,27 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def plan_calls(K, W, S, world, rank, tiles=False, weak=False, split_each_step=False):
+    """The sample ranges [begin, end) of the render calls `rank` makes for the timed job of K steps of S samples per
+    pixel (weak scaling: S per rank and step) that follows W warm-up steps.  Samples mode: the ranges of all ranks
+    partition the job's range; tiles mode: every rank covers the whole range (for its own rows), N steps to a call."""
+    step_spp = S * world if weak else S
+    job_lo, job_hi = W * step_spp, (W + K) * step_spp
+    if world == 1 or weak or split_each_step:
+        if weak:
+            calls = [(job_lo + k * step_spp + rank * S, job_lo + k * step_spp + (rank + 1) * S) for k in range(K)]
+        elif tiles or world == 1:
+            calls = [(job_lo + k * S, job_lo + (k + 1) * S) for k in range(K)]
+        else:
+            calls = [(job_lo + k * S + (S * rank) // world, job_lo + k * S + (S * (rank + 1)) // world) for k in range(K)]
+    elif tiles:
+        calls = [(c, min(c + world * S, job_hi)) for c in range(job_lo, job_hi, world * S)]
+    else:
+        lo, hi = job_lo + (K * S * rank) // world, job_lo + (K * S * (rank + 1)) // world
+        calls = [(c, min(c + S, hi)) for c in range(lo, hi, S)]
+    return [c for c in calls if c[1] > c[0]]
 
 
 def launch_ranks(n):

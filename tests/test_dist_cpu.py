@@ -101,3 +101,35 @@ def test_bench_passes_a_failing_rank_on():
                          cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
     assert res.returncode != 0
     assert res.stdout.strip() == ""
+
+
+def test_bench_call_plans_cover_the_job_exactly_once():
+    """bench.py --gpus N: whatever the split, the ranks' render calls together cover every sample of the timed job
+    exactly once (samples) or once per rank's rows (tiles), and no call is larger than one GPU's batch of S samples
+    per pixel (tiles: N steps' samples for a N-th of the rows)."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    for K, W, S in ((20, 5, 128), (3, 1, 128), (5, 0, 16), (1, 1, 2), (7, 2, 3)):
+        job = set(range(W * S, (W + K) * S))
+        for world in (1, 2, 3, 4, 8):
+            for split_each_step in (False, True):
+                seen = []
+                for rank in range(world):
+                    calls = bench.plan_calls(K, W, S, world, rank, split_each_step=split_each_step)
+                    assert all(0 < b - a <= S for a, b in calls)
+                    seen += [s for a, b in calls for s in range(a, b)]
+                assert len(seen) == len(job) and set(seen) == job, (K, W, S, world, split_each_step)
+                if world > 1 and not split_each_step and K * S >= world:
+                    # a rank's share comes in calls as large as the batch allows: at most one of them is short
+                    calls = bench.plan_calls(K, W, S, world, 0)
+                    assert sum(1 for a, b in calls if b - a < S) <= 1
+            for rank in range(world):  # tiles: every rank renders the whole range for its rows
+                calls = bench.plan_calls(K, W, S, world, rank, tiles=True)
+                assert sorted(s for a, b in calls for s in range(a, b)) == sorted(job)
+                assert all(b - a <= world * S for a, b in calls)
+            # weak scaling: K * world * S samples, every rank K calls of S
+            seen = [s for rank in range(world) for a, b in bench.plan_calls(K, W, S, world, rank, weak=True) for s in range(a, b)]
+            assert sorted(seen) == list(range(W * S * world, (W + K) * S * world))
