@@ -376,7 +376,10 @@ extern "C" int mipt_debug_isect(unsigned long long *out, int n) {
 // samples, RayTracer.cpp:72-75 calls trace(x, y) N times with the same x, y); only the first
 // ray of every run is traced, k_shade reads its result for the whole run.  n = rays to trace.
 // CAM: the level of the camera rays, computed from their index (`cam`) instead of read from `q`.
-template <bool COUNT, bool LOCAL, bool CAM>
+// LEAN (SceneDev::lean_any, never with CAM): the walk passes the few analytic primitives beside the meshes over — with their
+// tests compiled in the kernel needs 96 registers and 68 bytes of scratch per lane, without them 80 and 12 — and k_shade,
+// which reads the ray and its hit anyway, lets those primitives improve on the hit (analytic_override).
+template <bool COUNT, bool LOCAL, bool CAM, bool LEAN = false>
 __global__ void __launch_bounds__(kBlock, MIPT_TRAV_WAVES) k_intersect(SceneDev S, RenderConst rc, RayQueue q, uint32_t n, uint32_t dup,
                                                                         double *__restrict__ hit_t, int *__restrict__ hit_prim, DeviceCounters *dc,
                                                                         CameraRays cam) {
@@ -424,7 +427,7 @@ __global__ void __launch_bounds__(kBlock, MIPT_TRAV_WAVES) k_intersect(SceneDev 
     if (__ballot(!idle) == 0ull) break;
     const uint32_t want_idle = exhausted ? 64u : kRefillIdleClosest;
     do {
-      trav_round<false, COUNT, LOCAL>(T, S, stack, tc);
+      trav_round<false, COUNT, LOCAL, LEAN>(T, S, stack, tc);
       if (!idle && T.cur == MIPT_TRAV_DONE) {
         hit_t[ray] = T.best.t;
         hit_prim[ray] = T.best.prim;
@@ -569,6 +572,29 @@ __device__ __forceinline__ void path_node(const SceneDev &S, const RenderConst &
   r.wdir = wdir;
 }
 
+// The analytic primitives' share of a closest hit found by a walk over the triangles only (k_intersect<LEAN>): the same
+// update rule as inside the walk (prim_test: smaller t, ties by the reference's visiting order), so the result is the
+// one the full walk returns.  A primitive whose world box the ray cannot reach before its present hit is not tested.
+__device__ __forceinline__ uint32_t analytic_override(const SceneDev &S, d3 o, d3 d, int &prim, double &t) {
+  Trav T;
+  T.org = o;
+  T.dir = d;
+  T.best.t = t;
+  T.best.prim = prim;
+  T.tlimit = 0.0f;
+  T.cur = MIPT_TRAV_DONE;
+  T.sp = 0;
+  uint32_t tested = 0;
+  for (int k = 0; k < S.n_analytic; k++) {
+    if (!ray_meets_box(o, d, T.best.t, S.object_boxes + 6u * (S.prim_info[k] & 0x3fffffffu))) continue;
+    tested++;
+    prim_test<false, false, false, true>(T, S, (uint32_t)k);
+  }
+  prim = T.best.prim;
+  t = T.best.t;
+  return tested;
+}
+
 template <bool COUNT, bool CAM>
 #ifdef MIPT_SHADE_WAVES
 #define MIPT_SHADE_BOUNDS __launch_bounds__(kShadeBlock, MIPT_SHADE_WAVES)
@@ -587,6 +613,7 @@ __global__ void MIPT_SHADE_BOUNDS k_shade(SceneDev S, RenderConst rc, RayQueue q
   uint32_t slot = 0;
   int depth = 0;
   int hprim = -1;
+  uint32_t analytic_tests = 0;
   if (live) {
     const uint32_t hidx = dup > 1u ? idx - idx % dup : idx;  // the run's traced ray
     int prim = hprim = hit_prim[hidx];
@@ -605,7 +632,12 @@ __global__ void MIPT_SHADE_BOUNDS k_shade(SceneDev S, RenderConst rc, RayQueue q
       slot = q.slot[idx];
       depth = (int)q.depth[idx];
     }
-    path_node<CAM>(S, rc, o, d, T, key, slot, depth, prim, prim >= 0 ? hit_t[hidx] : 0.0, accum, r);  // CAM: one camera ray per sample
+    double t_hit = hit_t[hidx];  // a miss holds the walk's limit
+    if (!CAM && S.lean_any && S.n_analytic > 0) {
+      analytic_tests = analytic_override(S, o, d, prim, t_hit);
+      hprim = prim;
+    }
+    path_node<CAM>(S, rc, o, d, T, key, slot, depth, prim, prim >= 0 ? t_hit : 0.0, accum, r);  // CAM: one camera ray per sample
     if (CAM) {
       // The camera level visits every sample of the batch exactly once, before anything else adds to its sum: it
       // stores the sample's first term (zero for a sample that ends here) instead of adding it to a cleared array,
@@ -660,7 +692,10 @@ __global__ void MIPT_SHADE_BOUNDS k_shade(SceneDev S, RenderConst rc, RayQueue q
       bc->overflow = 1;
     }
   }
-  if (COUNT) wave_count(&dc->shaded_hits, shaded ? 1u : 0u);
+  if (COUNT) {
+    wave_count(&dc->shaded_hits, shaded ? 1u : 0u);
+    wave_count(&dc->closest_prims, analytic_tests);
+  }
 }
 
 // ------------------------------------------------------------------ shadow ----
@@ -1671,6 +1706,9 @@ void launch_intersect(const SceneDev &S, const RenderConst &rc, RayQueue q, uint
   uint32_t traced = n / dup;
   auto kern = S.local_meshes ? (count ? k_intersect<true, true, false> : k_intersect<false, true, false>)
                              : (count ? k_intersect<true, false, false> : k_intersect<false, false, false>);
+  if (!cam && S.lean_any != 0 && S.n_analytic <= kLeanAnalyticMax)  // triangles only; k_shade looks at the analytic primitives
+    kern = S.local_meshes ? (count ? k_intersect<true, true, false, true> : k_intersect<false, true, false, true>)
+                          : (count ? k_intersect<true, false, false, true> : k_intersect<false, false, false, true>);
   if (cam)
     kern = S.local_meshes ? (count ? k_intersect<true, true, true> : k_intersect<false, true, true>)
                           : (count ? k_intersect<true, false, true> : k_intersect<false, false, true>);
