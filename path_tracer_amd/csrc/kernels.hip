@@ -380,7 +380,10 @@ extern "C" int mipt_debug_isect(unsigned long long *out, int n) {
 // tests compiled in the kernel needs 96 registers and 68 bytes of scratch per lane, without them 80 and 12 — and k_shade,
 // which reads the ray and its hit anyway, lets those primitives improve on the hit (analytic_override).
 template <bool COUNT, bool LOCAL, bool CAM, bool LEAN = false>
-__global__ void __launch_bounds__(kBlock, MIPT_TRAV_WAVES) k_intersect(SceneDev S, RenderConst rc, RayQueue q, uint32_t n, uint32_t dup,
+#ifndef MIPT_LEAN_CLOSEST_WAVES
+#define MIPT_LEAN_CLOSEST_WAVES MIPT_TRAV_WAVES  // measured at 6 (80 registers, 12 B of scratch): see the sweep in DESIGN
+#endif
+__global__ void __launch_bounds__(kBlock, (LEAN ? MIPT_LEAN_CLOSEST_WAVES : MIPT_TRAV_WAVES)) k_intersect(SceneDev S, RenderConst rc, RayQueue q, uint32_t n, uint32_t dup,
                                                                         double *__restrict__ hit_t, int *__restrict__ hit_prim, DeviceCounters *dc,
                                                                         CameraRays cam) {
   extern __shared__ uint32_t lds_stack[];
@@ -1706,14 +1709,15 @@ void launch_intersect(const SceneDev &S, const RenderConst &rc, RayQueue q, uint
   uint32_t traced = n / dup;
   auto kern = S.local_meshes ? (count ? k_intersect<true, true, false> : k_intersect<false, true, false>)
                              : (count ? k_intersect<true, false, false> : k_intersect<false, false, false>);
-  if (!cam && S.lean_any != 0 && S.n_analytic <= kLeanAnalyticMax)  // triangles only; k_shade looks at the analytic primitives
+  const bool lean = !cam && S.lean_any != 0 && S.n_analytic <= kLeanAnalyticMax;
+  if (lean)  // triangles only; k_shade looks at the analytic primitives
     kern = S.local_meshes ? (count ? k_intersect<true, true, false, true> : k_intersect<false, true, false, true>)
                           : (count ? k_intersect<true, false, false, true> : k_intersect<false, false, false, true>);
   if (cam)
     kern = S.local_meshes ? (count ? k_intersect<true, true, true> : k_intersect<false, true, true>)
                           : (count ? k_intersect<true, false, true> : k_intersect<false, false, true>);
   (void)hipMemsetAsync(dc->dyn_next, 0, sizeof(dc->dyn_next), st);
-  hipLaunchKernelGGL(kern, dim3(persistent_grid(S, rc, traced)), dim3(kBlock), stack_bytes(S), st, S, rc, q, traced, dup, hit_t, hit_prim, dc,
+  hipLaunchKernelGGL(kern, dim3(persistent_grid(S, rc, traced, lean ? MIPT_LEAN_CLOSEST_WAVES : MIPT_TRAV_WAVES)), dim3(kBlock), stack_bytes(S), st, S, rc, q, traced, dup, hit_t, hit_prim, dc,
                      cam ? *cam : CameraRays{nullptr, 0, 0, 0, 1});
 }
 
