@@ -803,6 +803,8 @@ static int render_core(mipt_ctx *c, const mipt_params *p, double *d_sum, hipStre
   const int *d_rows = reinterpret_cast<const int *>(ws.rows);
   mipt_counters &tot = c->totals;
 
+  // lean scenes: the sum kernel looks at the few analytic primitives the shadow walk passes over, where it is one of the kernels that can
+  const bool analytic_in_sum = shadow_sum_takes_analytic(c->dev);
   for (int64_t p0 = 0; p0 < owned; p0 += PB) {
     int npix = (int)std::min<int64_t>(PB, owned - p0);
     for (int s0 = p->sample_begin; s0 < p->sample_end; s0 += SB) {
@@ -925,11 +927,11 @@ static int render_core(mipt_ctx *c, const mipt_params *p, double *d_sum, hipStre
           uint32_t nh = (uint32_t)std::min<uint64_t>(hits_per_chunk, h.shades - h0);
           {
             ProfScope ps(c, prof, MIPT_K_SHADOW, (uint64_t)nh * rays_per_hit, sb);
-            launch_shadow_trace(halves ? dev_b : c->dev, rc, sl_l, h0, nh, vis, halves ? dc + 1 : dc, count, sb);
+            launch_shadow_trace(halves ? dev_b : c->dev, rc, sl_l, h0, nh, vis, halves ? dc + 1 : dc, count, sb, analytic_in_sum);
           }
           {
             ProfScope ps(c, prof, MIPT_K_SHADOW_SUM, nh, sb);
-            launch_shadow_sum(c->dev, sl_l, h0, nh, vis, accum, cam_level && !halves, sb);
+            launch_shadow_sum(c->dev, rc, sl_l, h0, nh, vis, accum, cam_level && !halves, sb, analytic_in_sum);
           }
         }
         if (halves && h.shades) {

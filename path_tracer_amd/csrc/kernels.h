@@ -91,11 +91,15 @@ void launch_copy_rays(RayQueue src, uint64_t src_off, RayQueue dst, uint64_t dst
 // vis: scratch for the per-ray shadow results, room for vis_rays rays (1 double each, 3 in
 // translucent scenes); the hits are processed in chunks that fit it.
 int traversal_blocks_per_cu(const SceneDev &S);
+// analytic_in_sum: the caller's launch_shadow_sum takes the analytic primitives' share of a lean launch (it must pass the same flag,
+// and shadow_sum_takes_analytic(S) must hold); else a pass behind the walk clears the records of the rays they block.
+bool shadow_sum_takes_analytic(const SceneDev &S);
 void launch_shadow_trace(const SceneDev &S, const RenderConst &rc, ShadeList sl, uint64_t first_hit, uint32_t n_hits, double *vis,
-                         DeviceCounters *dc, bool count, hipStream_t st);
+                         DeviceCounters *dc, bool count, hipStream_t st, bool analytic_in_sum = false);
 // alone: every hit belongs to another sample and no other launch that adds to the samples' sums runs beside this
 // one (the hits of a batch's camera rays on the caller's stream): plain additions instead of atomics.
-void launch_shadow_sum(const SceneDev &S, ShadeList sl, uint64_t first_hit, uint32_t n_hits, const double *vis, double *accum, bool alone, hipStream_t st);
+void launch_shadow_sum(const SceneDev &S, const RenderConst &rc, ShadeList sl, uint64_t first_hit, uint32_t n_hits, const double *vis, double *accum, bool alone,
+                       hipStream_t st, bool analytic_in_sum = false);
 void launch_resolve(const RenderConst &rc, const double *accum, const int *rows, int64_t first_pixel, int n_pixels,
                     int n_samples, double *d_sum, DeviceCounters *dc, hipStream_t st);
 void launch_finalize(const double *d_sum, int64_t n_pixels, int spp, float *rgb_f32, uint8_t *rgb8, hipStream_t st);

@@ -939,13 +939,90 @@ __device__ __forceinline__ LightRec load_light_uniform(const LightRec *p) {
   return L;
 }
 
-// The analytic primitives' share of a LEAN shadow launch, one lane per hit, light after light.  Every shadow ray
-// of a (hit, light) pair runs from the hit's firing point to a point of the light's box of sample points
-// (light.cpp:109), so it stays inside the shaft between the two — at parameter t the box
-// [F + t (B.lo - F), F + t (B.hi - F)] — and a primitive whose (slightly grown) world box the shaft misses blocks
-// none of them: almost every pair ends there, most of them without a division.  For the others the pair's rays
-// are set up as in k_shadow_any and tested against that primitive, and the records of blocked rays are cleared
-// (this launch follows k_shadow_any's on the same stream).
+// The analytic primitives' share of a LEAN shadow launch.  Every shadow ray of a (hit, light) pair runs from the hit's
+// firing point to a point of the light's box of sample points (light.cpp:109), so it stays inside the shaft between the
+// two — at parameter t the box [F + t (B.lo - F), F + t (B.hi - F)] — and a primitive whose (slightly grown) world box the
+// shaft misses blocks none of them: almost every pair ends there, most of them without a division.
+// analytic_candidates: the primitives (bit k = primitive k, at most kLeanAnalyticMax of them) the pair's rays can meet.
+// analytic_blocks: does one of those block the pair's sample `sidx`?  (The ray is set up as in k_shadow_any.)
+__device__ __forceinline__ uint32_t analytic_candidates(const SceneDev &S, const RenderConst &rc, const LightRec &L, d3 fire, d3 N, uint32_t own) {
+  const double f[3] = {fire.x, fire.y, fire.z}, nn[3] = {N.x, N.y, N.z};
+  const bool directional = L.type == MIPT_LIGHT_DIRECTIONAL;
+  double dl[3], dh[3];  // the light's box of sample points relative to the firing point (directional: the ray's far end)
+#pragma unroll
+  for (int a = 0; a < 3; a++) {
+    double lo, hi;
+    if (directional) {
+      lo = hi = f[a] - L.orientation[a] * rc.t_max;
+    } else if (L.type == MIPT_LIGHT_RECT_AREA) {
+      const double base = L.position[a] + L.v[a], du = L.u[a] * L.uL;
+      lo = base + fmin(0.0, du) + fmin(0.0, L.vL);
+      hi = base + fmax(0.0, du) + fmax(0.0, L.vL);
+    } else {
+      lo = hi = L.position[a];
+    }
+    const double grow = 1e-9 * (S.radius + 1.0 + fabs(lo) + fabs(hi));  // far more than the rounding of a sample point
+    dl[a] = (lo - grow) - f[a];
+    dh[a] = (hi + grow) - f[a];
+  }
+  // Do all rays of the pair leave the surface the hit lies on (N.dir > 1e-6 for every sample point)?  Then a
+  // convex primitive — sphere, box or square — cannot block the rays that start 3e-8 above it, by a margin far
+  // beyond the rounding of its test: the pair skips the primitive its hit lies on, whose box the shaft always
+  // meets (the hits on a floor square would otherwise set up all their rays to learn nothing).
+  double least = 0.0, far2 = 0.0;
+#pragma unroll
+  for (int a = 0; a < 3; a++) {
+    least += fmin(nn[a] * dl[a], nn[a] * dh[a]);
+    far2 += fmax(dl[a] * dl[a], dh[a] * dh[a]);
+  }
+  const bool leaving = least > 1e-6 * sqrt(far2);
+  uint32_t mask = 0;
+  for (int k = 0; k < S.n_analytic; k++) {
+    if (leaving && own == (uint32_t)k) continue;
+    const double *b = S.object_boxes + 6u * (S.prim_info[k] & 0x3fffffffu);
+    // first without a division: on some axis the box lies beside everything between the firing point and the light
+    bool apart = false;
+#pragma unroll
+    for (int a = 0; a < 3; a++) apart = apart || b[3 + a] - f[a] < fmin(0.0, dl[a]) || b[a] - f[a] > fmax(0.0, dh[a]);
+    if (apart) continue;
+    // some t in [0, 1] with F + t dl <= b.hi and F + t dh >= b.lo on every axis: two half-lines in t per axis
+    double t0 = 0.0, t1 = 1.0;
+    bool ok = true;
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+      const double up = b[3 + a] - f[a], dn = b[a] - f[a];
+      if (dl[a] > 0.0) t1 = fmin(t1, up / dl[a]);
+      else if (dl[a] < 0.0) t0 = fmax(t0, up / dl[a]);
+      else ok = ok && up >= 0.0;
+      if (dh[a] > 0.0) t0 = fmax(t0, dn / dh[a]);
+      else if (dh[a] < 0.0) t1 = fmin(t1, dn / dh[a]);
+      else ok = ok && dn <= 0.0;
+    }
+    if (ok && t0 <= t1 * (1.0 + 1e-12) + 1e-12) mask |= 1u << k;
+  }
+  return mask;
+}
+__device__ __forceinline__ bool analytic_blocks(const SceneDev &S, const RenderConst &rc, const LightRec &L, int li, int sidx, d3 fire, uint64_t key, uint32_t mask) {
+  const ShadowSetup su = shadow_setup(rc, L, li, sidx, fire, key);
+  Trav T;
+  T.org = fire;
+  T.dir = su.dir;
+  T.best.t = fmin(su.lightT, rc.t_max);
+  T.best.prim = -1;
+  T.tlimit = 0.0f;
+  T.cur = MIPT_TRAV_DONE;
+  T.sp = 0;
+  for (uint32_t m = mask; m != 0u; m &= m - 1u) {
+    const uint32_t k = (uint32_t)__ffs((int)m) - 1u;
+    if (!ray_meets_box(T.org, T.dir, T.best.t, S.object_boxes + 6u * (S.prim_info[k] & 0x3fffffffu))) continue;
+    if (prim_test<true, false, false, true>(T, S, k)) return true;
+  }
+  return false;
+}
+
+// One lane per hit, light after light: the records of the rays the analytic primitives block are cleared (this launch
+// follows k_shadow_any's on the same stream).  Renders whose sum kernel looks at those primitives itself
+// (shadow_sum_takes_analytic) do not launch it.
 template <bool LOCAL>
 __global__ void __launch_bounds__(kBlock) k_shadow_analytic(SceneDev S, RenderConst rc, ShadeList sl, uint32_t first_hit, uint32_t n_hits, double *vis) {
   const uint32_t hl = blockIdx.x * kBlock + threadIdx.x;
@@ -955,77 +1032,15 @@ __global__ void __launch_bounds__(kBlock) k_shadow_analytic(SceneDev S, RenderCo
   const d3 N{sl.nx[h], sl.ny[h], sl.nz[h]};
   const uint32_t own = sl.prim[h];
   const d3 fire = P + (N * MIPT_RAY_EPSILON) * 3.0;  // material.cpp:117
-  const double f[3] = {fire.x, fire.y, fire.z}, nn[3] = {N.x, N.y, N.z};
   for (int li = 0; li < S.n_lights; li++) {
     const LightRec L = load_light_uniform(S.lights + li);
-    const bool directional = L.type == MIPT_LIGHT_DIRECTIONAL;
-    double dl[3], dh[3];  // the light's box of sample points relative to the firing point (directional: the ray's far end)
-#pragma unroll
-    for (int a = 0; a < 3; a++) {
-      double lo, hi;
-      if (directional) {
-        lo = hi = f[a] - L.orientation[a] * rc.t_max;
-      } else if (L.type == MIPT_LIGHT_RECT_AREA) {
-        const double base = L.position[a] + L.v[a], du = L.u[a] * L.uL;
-        lo = base + fmin(0.0, du) + fmin(0.0, L.vL);
-        hi = base + fmax(0.0, du) + fmax(0.0, L.vL);
-      } else {
-        lo = hi = L.position[a];
-      }
-      const double grow = 1e-9 * (S.radius + 1.0 + fabs(lo) + fabs(hi));  // far more than the rounding of a sample point
-      dl[a] = (lo - grow) - f[a];
-      dh[a] = (hi + grow) - f[a];
-    }
-    // Do all rays of the pair leave the surface the hit lies on (N.dir > 1e-6 for every sample point)?  Then a
-    // convex primitive — sphere, box or square — cannot block the rays that start 3e-8 above it, by a margin far
-    // beyond the rounding of its test: the pair skips the primitive its hit lies on, whose box the shaft always
-    // meets (the hits on a floor square would otherwise set up all their rays here to learn nothing).
-    double least = 0.0, far2 = 0.0;
-#pragma unroll
-    for (int a = 0; a < 3; a++) {
-      least += fmin(nn[a] * dl[a], nn[a] * dh[a]);
-      far2 += fmax(dl[a] * dl[a], dh[a] * dh[a]);
-    }
-    const bool leaving = least > 1e-6 * sqrt(far2);
-    for (int k = 0; k < S.n_analytic; k++) {
-      if (leaving && own == (uint32_t)k) continue;
-      const double *b = S.object_boxes + 6u * (S.prim_info[k] & 0x3fffffffu);
-      // first without a division: on some axis the box lies beside everything between the firing point and the light
-      bool apart = false;
-#pragma unroll
-      for (int a = 0; a < 3; a++) apart = apart || b[3 + a] - f[a] < fmin(0.0, dl[a]) || b[a] - f[a] > fmax(0.0, dh[a]);
-      if (apart) continue;
-      // some t in [0, 1] with F + t dl <= b.hi and F + t dh >= b.lo on every axis: two half-lines in t per axis
-      double t0 = 0.0, t1 = 1.0;
-      bool ok = true;
-#pragma unroll
-      for (int a = 0; a < 3; a++) {
-        const double up = b[3 + a] - f[a], dn = b[a] - f[a];
-        if (dl[a] > 0.0) t1 = fmin(t1, up / dl[a]);
-        else if (dl[a] < 0.0) t0 = fmax(t0, up / dl[a]);
-        else ok = ok && up >= 0.0;
-        if (dh[a] > 0.0) t0 = fmax(t0, dn / dh[a]);
-        else if (dh[a] < 0.0) t1 = fmin(t1, dn / dh[a]);
-        else ok = ok && dn <= 0.0;
-      }
-      if (!(ok && t0 <= t1 * (1.0 + 1e-12) + 1e-12)) continue;
-      for (int sidx = 0; sidx < L.samples; sidx++) {
-        const ShadowSetup su = shadow_setup(rc, L, li, sidx, fire, sl.key[h]);
-        Trav T;
-        T.org = fire;
-        T.dir = su.dir;
-        T.best.t = fmin(su.lightT, rc.t_max);
-        T.best.prim = -1;
-        T.tlimit = 0.0f;
-        T.cur = MIPT_TRAV_DONE;
-        T.sp = 0;
-        if (!ray_meets_box(T.org, T.dir, T.best.t, b)) continue;
-        if (prim_test<true, LOCAL>(T, S, (uint32_t)k)) {
-          const uint64_t item = (uint64_t)hl * (uint32_t)S.rays_per_hit + (uint32_t)(L.first_ray + sidx);
-          if (S.vis_bytes) reinterpret_cast<uint8_t *>(vis)[item] = 0;
-          else vis[item] = 0.0;
-        }
-      }
+    const uint32_t mask = analytic_candidates(S, rc, L, fire, N, own);
+    if (!mask) continue;
+    for (int sidx = 0; sidx < L.samples; sidx++) {
+      if (!analytic_blocks(S, rc, L, li, sidx, fire, sl.key[h], mask)) continue;
+      const uint64_t item = (uint64_t)hl * (uint32_t)S.rays_per_hit + (uint32_t)(L.first_ray + sidx);
+      if (S.vis_bytes) reinterpret_cast<uint8_t *>(vis)[item] = 0;
+      else vis[item] = 0.0;
     }
   }
 }
@@ -1140,8 +1155,10 @@ __global__ void __launch_bounds__(kBlock) k_shadow_sum_tiled(SceneDev S, ShadeLi
 // The same sum from one-byte visibility records (SceneDev::vis_bytes): a lane reads its hit's rays_per_hit
 // bytes, which lie side by side with its neighbours' (no staging through LDS), and adds the light's scale
 // for every ray that reached it: the additions, and their order, of the fp64 records' sum.
-template <bool ALONE>
-__global__ void __launch_bounds__(kBlock) k_shadow_sum_bytes(SceneDev S, ShadeList sl, uint32_t first_hit, uint32_t n_hits,
+// ANALYTIC (lean scenes): this kernel also looks at the few analytic primitives the shadow walk passed over — a ray one of them
+// blocks counts as a ray that did not arrive — instead of a pass of its own over the same records clearing them first.
+template <bool ALONE, bool ANALYTIC>
+__global__ void __launch_bounds__(kBlock) k_shadow_sum_bytes(SceneDev S, RenderConst rc, ShadeList sl, uint32_t first_hit, uint32_t n_hits,
                                                               const uint8_t *__restrict__ vis8, double *accum) {
   uint32_t i = blockIdx.x * kBlock + threadIdx.x;
   if (i >= n_hits) return;
@@ -1150,11 +1167,17 @@ __global__ void __launch_bounds__(kBlock) k_shadow_sum_bytes(SceneDev S, ShadeLi
   d3 N{sl.nx[h], sl.ny[h], sl.nz[h]};
   d3 Wt{sl.wx[h], sl.wy[h], sl.wz[h]};
   const uint8_t *v = vis8 + (uint64_t)i * (uint32_t)S.rays_per_hit;
+  const d3 fire = P + (N * MIPT_RAY_EPSILON) * 3.0;  // material.cpp:117
   d3 total{0, 0, 0};
   for (int li = 0; li < S.n_lights; li++) {
     const LightRec &L = S.lights[li];
+    const uint32_t mask = ANALYTIC ? analytic_candidates(S, rc, L, fire, N, sl.prim[h]) : 0u;
     d3 sum{0, 0, 0};
-    for (int s = 0; s < L.samples; s++) sum = sum + ld3(L.color) * (v[L.first_ray + s] ? L.flat_scale : 0.0);
+    for (int s = 0; s < L.samples; s++) {
+      bool arrived = v[L.first_ray + s] != 0;
+      if (ANALYTIC && mask != 0u && arrived) arrived = !analytic_blocks(S, rc, L, li, s, fire, sl.key[h], mask);
+      sum = sum + ld3(L.color) * (arrived ? L.flat_scale : 0.0);
+    }
     if (L.type == MIPT_LIGHT_RECT_AREA) sum = sum / (double)L.samples;  // light.cpp:145
     double f = distance_attenuation(L, P) * fabs(dot(N, light_direction(L, P)));
     total = total + (sum * f) * Wt;
@@ -1168,7 +1191,8 @@ __global__ void __launch_bounds__(kBlock) k_shadow_sum_bytes(SceneDev S, ShadeLi
 // every cache line when there are hundreds of rays per hit.  Here adjacent lanes read adjacent
 // runs of `samples` doubles, evaluate their light once, and the lanes of one hit (adjacent, a
 // run may straddle waves) are added with a segmented shuffle reduction before the deposit.
-__global__ void __launch_bounds__(kBlock) k_shadow_sum_lights(SceneDev S, ShadeList sl, uint32_t first_hit, uint32_t n_hits,
+template <bool ANALYTIC>  // as in k_shadow_sum_bytes
+__global__ void __launch_bounds__(kBlock) k_shadow_sum_lights(SceneDev S, RenderConst rc, ShadeList sl, uint32_t first_hit, uint32_t n_hits,
                                                                const double *__restrict__ vis, double *accum) {
   const uint64_t item = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
   const uint32_t nL = (uint32_t)S.n_lights;
@@ -1179,13 +1203,28 @@ __global__ void __launch_bounds__(kBlock) k_shadow_sum_lights(SceneDev S, ShadeL
   if (live) {
     const uint32_t li = (uint32_t)(item - (uint64_t)i * nL);
     const LightRec &L = S.lights[li];
+    uint32_t mask = 0u;
+    d3 fire{0, 0, 0};
+    if (ANALYTIC) {
+      const d3 Pa{sl.px[h], sl.py[h], sl.pz[h]}, Na{sl.nx[h], sl.ny[h], sl.nz[h]};
+      fire = Pa + (Na * MIPT_RAY_EPSILON) * 3.0;  // material.cpp:117
+      mask = analytic_candidates(S, rc, L, fire, Na, sl.prim[h]);
+    }
     double sum = 0.0;
     if (S.vis_bytes) {
       const uint8_t *v8 = reinterpret_cast<const uint8_t *>(vis) + (uint64_t)i * (uint32_t)S.rays_per_hit + (uint32_t)L.first_ray;
-      for (int s = 0; s < L.samples; s++) sum += v8[s] ? L.flat_scale : 0.0;
+      for (int s = 0; s < L.samples; s++) {
+        bool arrived = v8[s] != 0;
+        if (ANALYTIC && mask != 0u && arrived) arrived = !analytic_blocks(S, rc, L, (int)li, s, fire, sl.key[h], mask);
+        sum += arrived ? L.flat_scale : 0.0;
+      }
     } else {
       const double *v = vis + (uint64_t)i * (uint32_t)S.rays_per_hit + (uint32_t)L.first_ray;
-      for (int s = 0; s < L.samples; s++) sum += v[s];
+      for (int s = 0; s < L.samples; s++) {
+        double val = v[s];
+        if (ANALYTIC && mask != 0u && val != 0.0 && analytic_blocks(S, rc, L, (int)li, s, fire, sl.key[h], mask)) val = 0.0;
+        sum += val;
+      }
     }
     d3 col = ld3(L.color) * sum;
     if (L.type == MIPT_LIGHT_RECT_AREA) col = col / (double)L.samples;  // light.cpp:145
@@ -1764,7 +1803,7 @@ static ShadowAnyKernel shadow_any_kernel(bool count, bool local, bool vis8, bool
 }
 
 void launch_shadow_trace(const SceneDev &S, const RenderConst &rc, ShadeList sl, uint64_t first_hit, uint32_t n_hits, double *vis,
-                         DeviceCounters *dc, bool count, hipStream_t st) {
+                         DeviceCounters *dc, bool count, hipStream_t st, bool analytic_in_sum) {
   uint64_t R = (uint64_t)S.rays_per_hit;
   if (!n_hits || !R) return;
   uint32_t items = (uint32_t)(n_hits * R);
@@ -1778,22 +1817,30 @@ void launch_shadow_trace(const SceneDev &S, const RenderConst &rc, ShadeList sl,
     (void)hipMemsetAsync(dc->dyn_next, 0, sizeof(dc->dyn_next), st);
     hipLaunchKernelGGL(kern, dim3(persistent_grid(S, rc, items, lean ? MIPT_LEAN_WAVES : MIPT_TRAV_WAVES)), dim3(kBlock), stack_bytes(S), st, S, rc, sl,
                        (uint32_t)first_hit, items, vis, dc);
-    if (lean && S.n_analytic > 0)  // what the analytic primitives block, which the walk passed over
+    if (lean && S.n_analytic > 0 && !analytic_in_sum)  // what the analytic primitives block, which the walk passed over
       hipLaunchKernelGGL(S.local_meshes ? k_shadow_analytic<true> : k_shadow_analytic<false>, dim3(grid_for(n_hits)), dim3(kBlock), 0, st, S, rc, sl,
                          (uint32_t)first_hit, n_hits, vis);
   }
 }
 
-void launch_shadow_sum(const SceneDev &S, ShadeList sl, uint64_t first_hit, uint32_t n_hits, const double *vis, double *accum, bool alone, hipStream_t st) {
+// Lean scenes whose sum kernel is one of the two that look at the analytic primitives themselves.
+bool shadow_sum_takes_analytic(const SceneDev &S) {
+  const bool lean = !S.translucent && S.lean_any != 0 && S.n_analytic <= kLeanAnalyticMax && S.n_analytic > 0;
+  return lean && (S.n_lights > 4 || S.vis_bytes != 0);
+}
+
+void launch_shadow_sum(const SceneDev &S, const RenderConst &rc, ShadeList sl, uint64_t first_hit, uint32_t n_hits, const double *vis, double *accum, bool alone,
+                       hipStream_t st, bool analytic_in_sum) {
   if (!n_hits || !S.rays_per_hit) return;
+  const bool analytic = analytic_in_sum && shadow_sum_takes_analytic(S);
   if (!S.translucent && S.n_lights > 4) {
-    hipLaunchKernelGGL(k_shadow_sum_lights, dim3(grid_for((uint64_t)n_hits * (uint64_t)S.n_lights)), dim3(kBlock), 0, st, S, sl, (uint32_t)first_hit,
-                       n_hits, vis, accum);
+    hipLaunchKernelGGL(analytic ? k_shadow_sum_lights<true> : k_shadow_sum_lights<false>, dim3(grid_for((uint64_t)n_hits * (uint64_t)S.n_lights)), dim3(kBlock), 0, st,
+                       S, rc, sl, (uint32_t)first_hit, n_hits, vis, accum);
     return;
   }
   if (S.vis_bytes) {
-    hipLaunchKernelGGL(alone ? k_shadow_sum_bytes<true> : k_shadow_sum_bytes<false>, dim3(grid_for(n_hits)), dim3(kBlock), 0, st, S, sl,
-                       (uint32_t)first_hit, n_hits, reinterpret_cast<const uint8_t *>(vis), accum);
+    auto kern = analytic ? (alone ? k_shadow_sum_bytes<true, true> : k_shadow_sum_bytes<false, true>) : (alone ? k_shadow_sum_bytes<true, false> : k_shadow_sum_bytes<false, false>);
+    hipLaunchKernelGGL(kern, dim3(grid_for(n_hits)), dim3(kBlock), 0, st, S, rc, sl, (uint32_t)first_hit, n_hits, reinterpret_cast<const uint8_t *>(vis), accum);
     return;
   }
   if (!S.translucent && S.rays_per_hit <= kSumTileRays && !MIPT_SUM_UNTILED) {
