@@ -589,7 +589,12 @@ __device__ __forceinline__ uint32_t analytic_override(const SceneDev &S, d3 o, d
   T.sp = 0;
   uint32_t tested = 0;
   for (int k = 0; k < S.n_analytic; k++) {
-    if (!ray_meets_box(o, d, T.best.t, S.object_boxes + 6u * (S.prim_info[k] & 0x3fffffffu))) continue;
+    const double *b = S.object_boxes + 6u * (S.prim_info[k] & 0x3fffffffu);
+    // first without a division: on some axis the box lies beside the whole segment up to the present hit (the boxes are
+    // grown by 1e-9 of the scene's size, far more than the rounding of the segment's end)
+    const d3 e = o + T.best.t * d;
+    if (fmax(o.x, e.x) < b[0] || fmin(o.x, e.x) > b[3] || fmax(o.y, e.y) < b[1] || fmin(o.y, e.y) > b[4] || fmax(o.z, e.z) < b[2] || fmin(o.z, e.z) > b[5]) continue;
+    if (!ray_meets_box(o, d, T.best.t, b)) continue;
     tested++;
     prim_test<false, false, false, true>(T, S, (uint32_t)k);
   }
