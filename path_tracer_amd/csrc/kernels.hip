@@ -1196,8 +1196,7 @@ __global__ void __launch_bounds__(kBlock) k_shadow_sum_bytes(SceneDev S, RenderC
 // every cache line when there are hundreds of rays per hit.  Here adjacent lanes read adjacent
 // runs of `samples` doubles, evaluate their light once, and the lanes of one hit (adjacent, a
 // run may straddle waves) are added with a segmented shuffle reduction before the deposit.
-template <bool ANALYTIC>  // as in k_shadow_sum_bytes
-__global__ void __launch_bounds__(kBlock) k_shadow_sum_lights(SceneDev S, RenderConst rc, ShadeList sl, uint32_t first_hit, uint32_t n_hits,
+__global__ void __launch_bounds__(kBlock) k_shadow_sum_lights(SceneDev S, ShadeList sl, uint32_t first_hit, uint32_t n_hits,
                                                                const double *__restrict__ vis, double *accum) {
   const uint64_t item = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
   const uint32_t nL = (uint32_t)S.n_lights;
@@ -1208,28 +1207,13 @@ __global__ void __launch_bounds__(kBlock) k_shadow_sum_lights(SceneDev S, Render
   if (live) {
     const uint32_t li = (uint32_t)(item - (uint64_t)i * nL);
     const LightRec &L = S.lights[li];
-    uint32_t mask = 0u;
-    d3 fire{0, 0, 0};
-    if (ANALYTIC) {
-      const d3 Pa{sl.px[h], sl.py[h], sl.pz[h]}, Na{sl.nx[h], sl.ny[h], sl.nz[h]};
-      fire = Pa + (Na * MIPT_RAY_EPSILON) * 3.0;  // material.cpp:117
-      mask = analytic_candidates(S, rc, L, fire, Na, sl.prim[h]);
-    }
     double sum = 0.0;
     if (S.vis_bytes) {
       const uint8_t *v8 = reinterpret_cast<const uint8_t *>(vis) + (uint64_t)i * (uint32_t)S.rays_per_hit + (uint32_t)L.first_ray;
-      for (int s = 0; s < L.samples; s++) {
-        bool arrived = v8[s] != 0;
-        if (ANALYTIC && mask != 0u && arrived) arrived = !analytic_blocks(S, rc, L, (int)li, s, fire, sl.key[h], mask);
-        sum += arrived ? L.flat_scale : 0.0;
-      }
+      for (int s = 0; s < L.samples; s++) sum += v8[s] ? L.flat_scale : 0.0;
     } else {
       const double *v = vis + (uint64_t)i * (uint32_t)S.rays_per_hit + (uint32_t)L.first_ray;
-      for (int s = 0; s < L.samples; s++) {
-        double val = v[s];
-        if (ANALYTIC && mask != 0u && val != 0.0 && analytic_blocks(S, rc, L, (int)li, s, fire, sl.key[h], mask)) val = 0.0;
-        sum += val;
-      }
+      for (int s = 0; s < L.samples; s++) sum += v[s];
     }
     d3 col = ld3(L.color) * sum;
     if (L.type == MIPT_LIGHT_RECT_AREA) col = col / (double)L.samples;  // light.cpp:145
@@ -1828,10 +1812,12 @@ void launch_shadow_trace(const SceneDev &S, const RenderConst &rc, ShadeList sl,
   }
 }
 
-// Lean scenes whose sum kernel is one of the two that look at the analytic primitives themselves.
+// Lean scenes whose sum kernel looks at the analytic primitives itself.
 bool shadow_sum_takes_analytic(const SceneDev &S) {
+  // (the lane-per-hit kernel of byte records only: in the kernel of many-light scenes, a lane per (hit, light), the same questions cost
+  // more than the pass they replace: config 5's sums 136 -> 247 ms per step for 37 ms less in the shadow launches)
   const bool lean = !S.translucent && S.lean_any != 0 && S.n_analytic <= kLeanAnalyticMax && S.n_analytic > 0;
-  return lean && (S.n_lights > 4 || S.vis_bytes != 0);
+  return lean && S.n_lights <= 4 && S.vis_bytes != 0;
 }
 
 void launch_shadow_sum(const SceneDev &S, const RenderConst &rc, ShadeList sl, uint64_t first_hit, uint32_t n_hits, const double *vis, double *accum, bool alone,
@@ -1839,8 +1825,8 @@ void launch_shadow_sum(const SceneDev &S, const RenderConst &rc, ShadeList sl, u
   if (!n_hits || !S.rays_per_hit) return;
   const bool analytic = analytic_in_sum && shadow_sum_takes_analytic(S);
   if (!S.translucent && S.n_lights > 4) {
-    hipLaunchKernelGGL(analytic ? k_shadow_sum_lights<true> : k_shadow_sum_lights<false>, dim3(grid_for((uint64_t)n_hits * (uint64_t)S.n_lights)), dim3(kBlock), 0, st,
-                       S, rc, sl, (uint32_t)first_hit, n_hits, vis, accum);
+    hipLaunchKernelGGL(k_shadow_sum_lights, dim3(grid_for((uint64_t)n_hits * (uint64_t)S.n_lights)), dim3(kBlock), 0, st, S, sl, (uint32_t)first_hit,
+                       n_hits, vis, accum);
     return;
   }
   if (S.vis_bytes) {
