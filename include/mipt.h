@@ -259,7 +259,7 @@ void mipt_destroy(mipt_ctx *ctx);
  *                  always use the host builder
  *   "leaf_max"     1..8, primitives per leaf the device builder aims for (default 2)
  *   "lds_stack"    1..24, traversal-stack entries per lane kept in LDS (default 24; the rest lives in HBM)
- *   "lean_any"     -1 = automatic, 0 = keep the analytic primitives' tests inside the shadow walk
+ *   "lean_any"     -1 = automatic, 0 = keep the analytic primitives' tests inside the shadow walk and the closest-hit walk
  *   "vis_bytes"    -1 = automatic, 0 = fp64 shadow-ray records, 1 = one byte wherever that is exact
  *   "tail_rays", "fuse_rays"   -1 = automatic, else the widest tree level (rays) that the depth-first
  *                  finishing launches take (0 = never)
