@@ -626,17 +626,20 @@ def _mesh_scene_with_analytic_occluders(seed=11):
 
 
 def test_analytic_primitives_beside_meshes_block_shadow_rays(oracle_lib, monkeypatch):
-    """In a mesh scene with a few analytic primitives the shadow walk passes those over and a pass per hit
-    (shaft of the hit's rays against the primitive's box, then the rays themselves) clears what they block;
-    MIPT_LEAN_ANY=0 keeps their tests in the walk.  Both must give the oracle's frame, shadows of the
+    """In a mesh scene with a few analytic primitives the shadow walk and the closest-hit walk pass those over: the
+    shading kernel lets them improve on a closest hit, and what they block is dropped either by a pass per hit behind
+    the shadow walk (shaft of the hit's rays against the primitive's box, then the rays themselves) or, with one-byte
+    records (MIPT_VIS_BYTES=1 here; the default in big scenes), by the sum kernel asking the same questions itself;
+    MIPT_LEAN_ANY=0 keeps their tests in both walks.  All three must give the oracle's frame, shadows of the
     analytic primitives on the meshes, on each other and on themselves included."""
     from path_tracer_amd.raytracer import Context
 
     sc = _mesh_scene_with_analytic_occluders()
     orc = oracle_lib.Oracle(sc)
     frames = []
-    for knob in ("1", "0"):
+    for knob, vis_bytes in (("1", "0"), ("0", "0"), ("1", "1")):
         monkeypatch.setenv("MIPT_LEAN_ANY", knob)
+        monkeypatch.setenv("MIPT_VIS_BYTES", vis_bytes)
         ctx = Context(0)
         try:
             ctx.upload_scene(sc)
@@ -651,7 +654,7 @@ def test_analytic_primitives_beside_meshes_block_shadow_rays(oracle_lib, monkeyp
             frames.append(f32.astype(np.float64))
         finally:
             ctx.close()
-    assert np.abs(frames[0] - frames[1]).max() <= 1e-6
+    assert np.abs(frames[0] - frames[1]).max() <= 1e-6 and np.abs(frames[0] - frames[2]).max() <= 1e-6
 
 
 def test_one_byte_visibility_records_give_the_fp64_records_frame(scenes, monkeypatch):
